@@ -1,0 +1,204 @@
+/*
+ * vk_radix_sort.h -- MI355X (gfx950 / HIP) backend behind the VrdxSorter / vrdxCmdSort* surface.
+ *
+ * This is the drop-in boundary: a C-ABI shared library (libvrdx_hip.so) exporting the eight
+ * entry points the reference declares at src/vk_radix_sort.h.in:24-81 (generated copy
+ * include/vk_radix_sort.h:24-81), with the same names, parameter order and parameter types.
+ * The reference is a header-only C++ library whose declarations have C++ linkage; here they are
+ * `extern "C"` so that any FFI (ctypes, cgo, JNI, N-API) can bind them.
+ *
+ * Vulkan handle types keep their reference spelling.  When <vulkan/vulkan_core.h> is available it
+ * is used; otherwise the minimal shim below supplies ABI-identical typedefs (every dispatchable
+ * and non-dispatchable handle is an 8-byte pointer on 64-bit targets).
+ *
+ * HIP meaning of each handle:
+ *   VkPhysicalDevice / VkDevice : HIP device ordinal, encoded with VRDX_HIP_DEVICE(ordinal);
+ *                                 VK_NULL_HANDLE = the calling thread's current HIP device.
+ *   VkPipelineCache             : ignored (kernels are precompiled for gfx950; no JIT).
+ *   VkCommandBuffer             : hipStream_t.  "Recording" is a stream-ordered enqueue; nothing
+ *                                 blocks the host, and the calls are legal inside
+ *                                 hipStreamBeginCapture/EndCapture (hipGraph) when queryPool is NULL.
+ *   VkBuffer + VkDeviceSize     : device pointer + byte offset.
+ *   VkQueryPool                 : VrdxHipQueryPool (array of hipEvent_t), see vrdxHipCreateQueryPool.
+ *
+ * All arithmetic on this path is 32-bit unsigned integer; keys are sorted ascending, the sort is
+ * stable, and results land back in keysBuffer / valuesBuffer (4 ping-pong passes).
+ */
+#ifndef VK_RADIX_SORT_H
+#define VK_RADIX_SORT_H
+
+#include <stdint.h>
+
+#if defined(__has_include)
+#if __has_include(<vulkan/vulkan_core.h>)
+#include <vulkan/vulkan_core.h>
+#define VRDX_HAVE_VULKAN_CORE 1
+#endif
+#endif
+
+#ifndef VRDX_HAVE_VULKAN_CORE
+/* ---- minimal Vulkan type shim (ABI-identical to vulkan_core.h on LP64) ---- */
+#ifndef VK_DEFINE_HANDLE
+#define VK_DEFINE_HANDLE(object) typedef struct object##_T* object;
+#endif
+#ifndef VK_NULL_HANDLE
+#define VK_NULL_HANDLE 0
+#endif
+typedef struct VkPhysicalDevice_T* VkPhysicalDevice;
+typedef struct VkDevice_T* VkDevice;
+typedef struct VkPipelineCache_T* VkPipelineCache;
+typedef struct VkCommandBuffer_T* VkCommandBuffer;
+typedef struct VkBuffer_T* VkBuffer;
+typedef struct VkQueryPool_T* VkQueryPool;
+typedef uint64_t VkDeviceSize;
+typedef uint32_t VkFlags;
+typedef VkFlags VkBufferUsageFlags;
+typedef enum VkResult {
+  VK_SUCCESS = 0,
+  VK_NOT_READY = 1,
+  VK_ERROR_OUT_OF_HOST_MEMORY = -1,
+  VK_ERROR_OUT_OF_DEVICE_MEMORY = -2,
+  VK_ERROR_INITIALIZATION_FAILED = -3,
+  VK_ERROR_DEVICE_LOST = -4,
+  VK_ERROR_FEATURE_NOT_PRESENT = -8,
+  VK_RESULT_MAX_ENUM = 0x7FFFFFFF
+} VkResult;
+#define VK_BUFFER_USAGE_TRANSFER_DST_BIT 0x00000002
+#define VK_BUFFER_USAGE_STORAGE_BUFFER_BIT 0x00000020
+#endif /* !VRDX_HAVE_VULKAN_CORE */
+
+/* reference: src/vk_radix_sort.h.in:6-9 (v0.4.0, CMakeLists.txt:3) */
+#define VRDX_VERSION_MAJOR 0
+#define VRDX_VERSION_MINOR 4
+#define VRDX_VERSION_PATCH 0
+#define VRDX_VERSION ((VRDX_VERSION_MAJOR << 22) | (VRDX_VERSION_MINOR << 12) | VRDX_VERSION_PATCH)
+
+/* HIP device ordinal <-> VkDevice / VkPhysicalDevice encoding (ordinal + 1 so that 0 stays NULL). */
+#define VRDX_HIP_DEVICE(ordinal) ((VkDevice)(uintptr_t)((ordinal) + 1))
+#define VRDX_HIP_PHYSICAL_DEVICE(ordinal) ((VkPhysicalDevice)(uintptr_t)((ordinal) + 1))
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+struct VrdxSorter_T;
+
+/* reference: src/vk_radix_sort.h.in:11-16 -- VrdxSorter owns the (precompiled) kernels' launch
+ * configuration for one device; immutable after creation. */
+VK_DEFINE_HANDLE(VrdxSorter)
+
+/* reference: src/vk_radix_sort.h.in:18-22 */
+typedef struct VrdxSorterCreateInfo {
+  VkPhysicalDevice physicalDevice;
+  VkDevice device;
+  VkPipelineCache pipelineCache;
+} VrdxSorterCreateInfo;
+
+/* reference: src/vk_radix_sort.h.in:24,141-265.  Returns VK_SUCCESS, or
+ * VK_ERROR_INITIALIZATION_FAILED (no usable HIP device / ordinal out of range),
+ * VK_ERROR_FEATURE_NOT_PRESENT (device is not gfx950), VK_ERROR_OUT_OF_HOST_MEMORY.
+ * On failure *pSorter is left untouched and nothing is leaked (reference cleanup(), :153-158). */
+VkResult vrdxCreateSorter(const VrdxSorterCreateInfo* pCreateInfo, VrdxSorter* pSorter);
+
+/* reference: src/vk_radix_sort.h.in:26,267-277.  NULL-safe. */
+void vrdxDestroySorter(VrdxSorter sorter);
+
+/* reference: src/vk_radix_sort.h.in:28-31 */
+typedef struct VrdxSorterStorageRequirements {
+  VkDeviceSize size;
+  VkBufferUsageFlags usage;
+} VrdxSorterStorageRequirements;
+
+/* reference: src/vk_radix_sort.h.in:33,279-292.  Same formula, bit for bit:
+ *   size = Align(4,A) + HistogramSize(N,A) + InoutSize(N,A), usage = STORAGE_BUFFER|TRANSFER_DST. */
+void vrdxGetSorterStorageRequirements(VrdxSorter sorter, uint32_t maxElementCount,
+                                      VrdxSorterStorageRequirements* requirements);
+
+/* reference: src/vk_radix_sort.h.in:36,294-308.
+ *   size = Align(4,A) + HistogramSize + Align(InoutSize,A) + InoutSize. */
+void vrdxGetSorterKeyValueStorageRequirements(VrdxSorter sorter, uint32_t maxElementCount,
+                                              VrdxSorterStorageRequirements* requirements);
+
+/**
+ * reference: src/vk_radix_sort.h.in:39-54,310-315.
+ *
+ * if queryPool is not VK_NULL_HANDLE, it records timestamps into N entries [query..query+N-1].
+ *
+ * N=15 (same slot contract as the reference):
+ * query + 0: start
+ * query + 1: after the state clear ("transfer")
+ * query + 2 + (3 * i) + 0: upsweep of pass i   (ours: the fused 4-digit histogram for i = 0;
+ *                                               coincides with the previous slot for i > 0)
+ * query + 2 + (3 * i) + 1: spine of pass i     (ours: always coincides with the slot before --
+ *                                               the scan is a decoupled look-back inside downsweep)
+ * query + 2 + (3 * i) + 2: downsweep of pass i (ours: the onesweep rank+scatter kernel)
+ * query + 14: sort end
+ */
+void vrdxCmdSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t elementCount,
+                 VkBuffer keysBuffer, VkDeviceSize keysOffset, VkBuffer storageBuffer,
+                 VkDeviceSize storageOffset, VkQueryPool queryPool, uint32_t query);
+
+/* reference: src/vk_radix_sort.h.in:55-58,317-323 */
+void vrdxCmdSortIndirect(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t maxElementCount,
+                         VkBuffer indirectBuffer, VkDeviceSize indirectOffset, VkBuffer keysBuffer,
+                         VkDeviceSize keysOffset, VkBuffer storageBuffer,
+                         VkDeviceSize storageOffset, VkQueryPool queryPool, uint32_t query);
+
+/* reference: src/vk_radix_sort.h.in:60-63,325-331 */
+void vrdxCmdSortKeyValue(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t elementCount,
+                         VkBuffer keysBuffer, VkDeviceSize keysOffset, VkBuffer valuesBuffer,
+                         VkDeviceSize valuesOffset, VkBuffer storageBuffer,
+                         VkDeviceSize storageOffset, VkQueryPool queryPool, uint32_t query);
+
+/**
+ * reference: src/vk_radix_sort.h.in:65-81,333-342.
+ *
+ * indirectBuffer contains elementCount: a uint32_t read on the device from
+ * indirectBuffer + indirectOffset when the sort executes.  It must not exceed maxElementCount
+ * (values above it are clamped).  Keys, values and the count may live in one buffer at different
+ * offsets (bench/vulkan_benchmark.cc:386-388).
+ */
+void vrdxCmdSortKeyValueIndirect(VkCommandBuffer commandBuffer, VrdxSorter sorter,
+                                 uint32_t maxElementCount, VkBuffer indirectBuffer,
+                                 VkDeviceSize indirectOffset, VkBuffer keysBuffer,
+                                 VkDeviceSize keysOffset, VkBuffer valuesBuffer,
+                                 VkDeviceSize valuesOffset, VkBuffer storageBuffer,
+                                 VkDeviceSize storageOffset, VkQueryPool queryPool, uint32_t query);
+
+/* ------------------------------------------------------------------------------------------
+ * HIP-side companions of the Vulkan objects the reference's callers create themselves
+ * (vkCreateQueryPool / vkGetQueryPoolResults, bench/vulkan_benchmark.cc:195-198,318-321).
+ * They are not part of the reference API; they exist so a caller without a Vulkan device can
+ * still use the 15-slot timestamp contract.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Creates a pool of `queryCount` timestamp slots (hipEvent_t each) on the current device. */
+VkResult vrdxHipCreateQueryPool(uint32_t queryCount, VkQueryPool* pQueryPool);
+void vrdxHipDestroyQueryPool(VkQueryPool queryPool);
+/* After the stream has completed: pData[i] = nanoseconds between slot firstQuery and slot
+ * firstQuery+i (so pData[0] == 0; timestampPeriod == 1.0).  Returns VK_NOT_READY if a slot was
+ * never recorded or has not completed. */
+VkResult vrdxHipGetQueryPoolResults(VkQueryPool queryPool, uint32_t firstQuery, uint32_t queryCount,
+                                    uint64_t* pData);
+
+/* Device-side failure word of the last sorts that used this storage: 0 = ok.  A non-zero value
+ * means a bounded look-back spin expired (the GPU never hangs; the output is then unspecified).
+ * Synchronises the given stream.  Diagnostic only. */
+uint32_t vrdxHipReadStatus(VkCommandBuffer commandBuffer, VkBuffer storageBuffer,
+                           VkDeviceSize storageOffset);
+
+/* Library build info: "vrdx-hip <version> gfx950 tile=<keys per tile>". */
+const char* vrdxHipVersionString(void);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#endif /* VK_RADIX_SORT_H */
+
+/* The reference is a single-header library activated with VRDX_IMPLEMENTATION
+ * (src/vk_radix_sort.h.in:85-86, bench/vrdx_impl.cc:1-4).  The HIP backend lives in
+ * libvrdx_hip.so, so the macro is accepted and ignored to keep such translation units compiling. */
+#ifdef VRDX_IMPLEMENTATION
+#undef VRDX_IMPLEMENTATION
+#endif

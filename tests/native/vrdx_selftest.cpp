@@ -1,0 +1,355 @@
+// vrdx_selftest.cpp -- native GPU parity + timing driver for libvrdx_hip.so (no Python, no torch).
+//
+// Calls the product exclusively through the C-ABI of include/vk_radix_sort.h and checks every
+// result bit for bit against the CPU oracle (oracle/liboracle.so: vrdx_oracle_sort).  Its checks
+// are the reference's own correctness predicate (bench/bench.cc:41-64 under /root/reference:
+// keys equal std::sort, keys+values equal std::stable_sort by key) extended to the edge cases
+// the reference never tests.
+//
+//   vrdx_selftest parity            # parity battery, exit code != 0 on any mismatch
+//   vrdx_selftest bench [log2n...]  # warm-up 1 + 10 timed runs per size, median (bench.cc:66-112)
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/vk_radix_sort.h"
+
+extern "C" {
+int vrdx_oracle_sort(uint32_t* keys, uint32_t* values, uint32_t elementCount, uint32_t* globalHistogramOut);
+uint64_t vrdx_oracle_storage_size(uint32_t maxElementCount, uint32_t align, int keyValue);
+}
+
+#define HIP_OK(x)                                                                      \
+  do {                                                                                 \
+    hipError_t e_ = (x);                                                               \
+    if (e_ != hipSuccess) {                                                            \
+      std::fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      std::exit(2);                                                                    \
+    }                                                                                  \
+  } while (0)
+
+namespace {
+
+constexpr uint32_t kGuard = 64;          // untouched-tail guard elements
+constexpr uint32_t kGuardWord = 0xDEADBEEFu;
+
+struct Harness {
+  VrdxSorter sorter = nullptr;
+  hipStream_t stream = nullptr;
+  uint8_t* dKeys = nullptr;     // keys | values | count, like bench/vulkan_benchmark.cc:386-388
+  uint8_t* dStorage = nullptr;
+  size_t keysCap = 0, storageCap = 0;
+  VkQueryPool pool = nullptr;
+
+  void init() {
+    VrdxSorterCreateInfo info = {};
+    VkResult r = vrdxCreateSorter(&info, &sorter);
+    if (r != VK_SUCCESS) {
+      std::fprintf(stderr, "vrdxCreateSorter failed: %d\n", (int)r);
+      std::exit(2);
+    }
+    HIP_OK(hipStreamCreate(&stream));
+    if (vrdxHipCreateQueryPool(15, &pool) != VK_SUCCESS) std::exit(2);
+  }
+  void reserve(size_t keysBytes, size_t storageBytes) {
+    if (keysBytes > keysCap) {
+      if (dKeys) HIP_OK(hipFree(dKeys));
+      HIP_OK(hipMalloc((void**)&dKeys, keysBytes));
+      keysCap = keysBytes;
+    }
+    if (storageBytes > storageCap) {
+      if (dStorage) HIP_OK(hipFree(dStorage));
+      HIP_OK(hipMalloc((void**)&dStorage, storageBytes));
+      storageCap = storageBytes;
+    }
+  }
+};
+
+enum class Mode { Keys, KeysIndirect, KeyValue, KeyValueIndirect };
+const char* ModeName(Mode m) {
+  switch (m) {
+    case Mode::Keys: return "keys";
+    case Mode::KeysIndirect: return "keys-indirect";
+    case Mode::KeyValue: return "kv";
+    default: return "kv-indirect";
+  }
+}
+
+uint32_t Align16(uint32_t x) { return (x + 15u) / 16u * 16u; }
+
+// One sort through the C-ABI + bit-exact comparison with the oracle.  `maxCount` >= n is what the
+// host passes in indirect mode (the device-side count is n).
+bool RunCase(Harness& h, Mode mode, const std::vector<uint32_t>& keys, const std::vector<uint32_t>& values,
+             uint32_t maxCount, const char* label, bool poisonStorage) {
+  const uint32_t n = (uint32_t)keys.size();
+  const bool kv = mode == Mode::KeyValue || mode == Mode::KeyValueIndirect;
+  const bool indirect = mode == Mode::KeysIndirect || mode == Mode::KeyValueIndirect;
+  if (!indirect) maxCount = n;
+
+  const uint32_t inout = Align16((maxCount + kGuard) * 4u);
+  VrdxSorterStorageRequirements req;
+  if (kv)
+    vrdxGetSorterKeyValueStorageRequirements(h.sorter, maxCount, &req);
+  else
+    vrdxGetSorterStorageRequirements(h.sorter, maxCount, &req);
+  if (req.size != vrdx_oracle_storage_size(maxCount, 16, kv ? 1 : 0) || req.usage != 0x22u) {
+    std::printf("FAIL %-34s %-12s n=%u storage requirement %llu (usage 0x%x) differs from the oracle\n", label,
+                ModeName(mode), n, (unsigned long long)req.size, req.usage);
+    return false;
+  }
+  const size_t guardBytes = 256;
+  h.reserve((size_t)2 * inout + 16, (size_t)req.size + guardBytes);
+
+  // host image: keys | values | count, tails poisoned
+  std::vector<uint32_t> hk(inout / 4, kGuardWord), hv(inout / 4, kGuardWord);
+  std::copy(keys.begin(), keys.end(), hk.begin());
+  if (kv) std::copy(values.begin(), values.end(), hv.begin());
+  HIP_OK(hipMemcpy(h.dKeys, hk.data(), inout, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(h.dKeys + inout, hv.data(), inout, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(h.dKeys + 2 * (size_t)inout, &n, 4, hipMemcpyHostToDevice));
+  // storage arrives with arbitrary contents; a guard band after it must survive
+  HIP_OK(hipMemset(h.dStorage, poisonStorage ? 0xA5 : 0x00, (size_t)req.size));
+  HIP_OK(hipMemset(h.dStorage + req.size, 0x5A, guardBytes));
+
+  VkCommandBuffer cmd = (VkCommandBuffer)h.stream;
+  VkBuffer buf = (VkBuffer)h.dKeys;
+  VkBuffer sto = (VkBuffer)h.dStorage;
+  switch (mode) {
+    case Mode::Keys: vrdxCmdSort(cmd, h.sorter, n, buf, 0, sto, 0, h.pool, 0); break;
+    case Mode::KeysIndirect:
+      vrdxCmdSortIndirect(cmd, h.sorter, maxCount, buf, 2 * (VkDeviceSize)inout, buf, 0, sto, 0, h.pool, 0);
+      break;
+    case Mode::KeyValue: vrdxCmdSortKeyValue(cmd, h.sorter, n, buf, 0, buf, inout, sto, 0, h.pool, 0); break;
+    case Mode::KeyValueIndirect:
+      vrdxCmdSortKeyValueIndirect(cmd, h.sorter, maxCount, buf, 2 * (VkDeviceSize)inout, buf, 0, buf, inout, sto,
+                                  0, h.pool, 0);
+      break;
+  }
+  HIP_OK(hipStreamSynchronize(h.stream));
+  const uint32_t failure = n ? vrdxHipReadStatus(cmd, sto, 0) : 0;
+
+  std::vector<uint32_t> gk(inout / 4), gv(inout / 4);
+  std::vector<uint8_t> guard(guardBytes);
+  HIP_OK(hipMemcpy(gk.data(), h.dKeys, inout, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(gv.data(), h.dKeys + inout, inout, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(guard.data(), h.dStorage + req.size, guardBytes, hipMemcpyDeviceToHost));
+
+  std::vector<uint32_t> ek = keys, ev = values;
+  vrdx_oracle_sort(ek.data(), kv ? ev.data() : nullptr, n, nullptr);
+
+  bool ok = failure == 0;
+  long firstBad = -1;
+  for (uint32_t i = 0; i < n && firstBad < 0; ++i)
+    if (gk[i] != ek[i] || (kv && gv[i] != ev[i])) firstBad = i;
+  if (firstBad >= 0) ok = false;
+  bool tailOk = true;
+  for (uint32_t i = n; i < inout / 4; ++i)
+    if (gk[i] != kGuardWord || gv[i] != kGuardWord) tailOk = false;
+  for (uint8_t b : guard)
+    if (b != 0x5A) tailOk = false;
+  if (!tailOk) ok = false;
+
+  uint64_t ts[15] = {0};
+  const VkResult tr = vrdxHipGetQueryPoolResults(h.pool, 0, 15, ts);
+  if (tr != VK_SUCCESS) ok = false;
+  for (int i = 1; i < 15 && tr == VK_SUCCESS; ++i)
+    if (ts[i] < ts[i - 1]) ok = false;
+
+  if (!ok) {
+    std::printf("FAIL %-34s %-12s n=%u max=%u failure=%u firstBad=%ld tailOk=%d ts=%d\n", label, ModeName(mode), n,
+                maxCount, failure, firstBad, (int)tailOk, (int)tr);
+    if (firstBad >= 0)
+      std::printf("     got key %08x val %08x, want key %08x val %08x\n", gk[firstBad], gv[firstBad], ek[firstBad],
+                  kv ? ev[firstBad] : 0u);
+  }
+  return ok;
+}
+
+std::vector<uint32_t> Mt(uint32_t n, int seed, uint32_t bits, std::vector<uint32_t>* values) {
+  // DataGenerator(seed).Generate(n, bits): keys then values from one mt19937 stream
+  std::mt19937 gen(seed);
+  std::vector<uint32_t> k(n);
+  for (auto& x : k) {
+    const uint32_t r = gen();
+    x = bits >= 32 ? r : (bits == 0 ? 0u : r >> (32 - bits));
+  }
+  if (values) {
+    values->resize(n);
+    for (auto& x : *values) x = gen();
+  }
+  return k;
+}
+
+int Parity(Harness& h, bool quick) {
+  int failures = 0, cases = 0;
+  auto run = [&](Mode m, const std::vector<uint32_t>& k, const std::vector<uint32_t>& v, uint32_t maxCount,
+                 const char* label, bool poison = true) {
+    ++cases;
+    if (!RunCase(h, m, k, v, maxCount, label, poison)) ++failures;
+  };
+  const Mode allModes[] = {Mode::Keys, Mode::KeyValue, Mode::KeysIndirect, Mode::KeyValueIndirect};
+
+  // sizes around every boundary of the reference (4096 partitions) and of our tiles (8192/16384)
+  std::vector<uint32_t> sizes = {0,     1,     2,     63,    64,    65,    511,   512,   513,   4095,
+                                 4096,  4097,  8191,  8192,  8193,  12411, 16383, 16384, 16385, 24577,
+                                 32768, 65539, 100000, 262144, 262145, 1u << 20, (1u << 20) + 7};
+  if (!quick) {
+    sizes.push_back(5000011);
+    sizes.push_back(1u << 24);
+  }
+  for (uint32_t n : sizes) {
+    for (int seed : {1, 42}) {
+      std::vector<uint32_t> v;
+      auto k = Mt(n, seed, 32, &v);
+      char label[64];
+      std::snprintf(label, sizeof(label), "mt19937 seed=%d", seed);
+      for (Mode m : allModes) {
+        const bool indirect = m == Mode::KeysIndirect || m == Mode::KeyValueIndirect;
+        if (indirect && seed != 1) continue;
+        // indirect: host bound larger than the device-side count (grid sized from max)
+        run(m, k, v, indirect ? n + n / 3 + 5000 : n, label);
+      }
+    }
+  }
+  // restricted-bit keys (Generate(n, bits), bench/data_generator.cc:15): heavy duplicates -> stability
+  for (uint32_t bits : {0u, 1u, 2u, 4u, 8u, 12u, 16u, 24u}) {
+    for (uint32_t n : {5000u, 70001u, 1u << 20}) {
+      std::vector<uint32_t> v;
+      auto k = Mt(n, 7, bits, &v);
+      std::vector<uint32_t> iota(n);
+      for (uint32_t i = 0; i < n; ++i) iota[i] = i;
+      char label[64];
+      std::snprintf(label, sizeof(label), "bits=%u values=iota", bits);
+      run(Mode::KeyValue, k, iota, n, label);
+      run(Mode::Keys, k, v, n, label);
+      // same digits in the HIGH byte(s): exercises passes 1..3 with skew
+      for (auto& x : k) x = (x << (32 - (bits ? bits : 1))) | (x & 0xFFu);
+      std::snprintf(label, sizeof(label), "bits=%u high values=iota", bits);
+      run(Mode::KeyValue, k, iota, n, label);
+    }
+  }
+  // adversarial (BASELINE.json configs[3]): all-equal, all-0xFFFFFFFF (== the padding sentinel),
+  // descending, ascending, few-distinct, per-pass digit skew
+  {
+    const uint32_t n = quick ? (1u << 20) + 12345 : (1u << 22) + 12345;
+    std::vector<uint32_t> iota(n), k(n);
+    for (uint32_t i = 0; i < n; ++i) iota[i] = i;
+    std::fill(k.begin(), k.end(), 0x12345678u);
+    run(Mode::KeyValue, k, iota, n, "all-equal 0x12345678");
+    std::fill(k.begin(), k.end(), 0xFFFFFFFFu);
+    run(Mode::KeyValue, k, iota, n, "all 0xFFFFFFFF (sentinel)");
+    std::fill(k.begin(), k.end(), 0u);
+    run(Mode::KeyValue, k, iota, n, "all zero");
+    for (uint32_t i = 0; i < n; ++i) k[i] = n - 1 - i;
+    run(Mode::KeyValue, k, iota, n, "descending");
+    run(Mode::Keys, k, iota, n, "descending");
+    for (uint32_t i = 0; i < n; ++i) k[i] = i;
+    run(Mode::KeyValue, k, iota, n, "ascending");
+    const uint32_t four[4] = {0xFFFFFFFFu, 0x00000000u, 0x80000001u, 0x7FFFFF00u};
+    std::mt19937 g(3);
+    for (uint32_t i = 0; i < n; ++i) k[i] = four[g() & 3];
+    run(Mode::KeyValue, k, iota, n, "few-distinct (4 values)");
+    for (int pass = 0; pass < 4; ++pass) {
+      for (uint32_t i = 0; i < n; ++i) {
+        uint32_t r = g();
+        k[i] = r & ~(0xFFu << (8 * pass));  // digit `pass` constant 0, the others random
+      }
+      char label[64];
+      std::snprintf(label, sizeof(label), "digit %d constant", pass);
+      run(Mode::KeyValue, k, iota, n, label);
+    }
+    // mixed sentinel keys and a ragged tail
+    for (uint32_t i = 0; i < n; ++i) k[i] = (g() & 7) ? g() : 0xFFFFFFFFu;
+    run(Mode::KeyValue, k, iota, n, "1/8 sentinel keys");
+  }
+  // zero-initialised storage must work as well as poisoned storage; and storage reuse back to back
+  {
+    std::vector<uint32_t> v;
+    auto k = Mt(300000, 5, 32, &v);
+    run(Mode::KeyValue, k, v, 300000, "clean storage", false);
+    run(Mode::KeyValue, k, v, 300000, "storage reuse");
+    run(Mode::Keys, k, v, 300000, "storage reuse");
+  }
+  std::printf("parity: %d cases, %d failures\n", cases, failures);
+  return failures;
+}
+
+uint64_t Median(std::vector<uint64_t> v) {
+  std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
+  return v[v.size() / 2];
+}
+
+void Bench(Harness& h, const std::vector<int>& logs) {
+  std::printf("%-10s %-6s %10s %10s %12s %10s %8s   stage ms (hist | scatter x4)\n", "n", "sort", "gpu_ms", "wall_ms",
+              "GItems/s", "GB/s", "%8TB/s");
+  for (int lg : logs) {
+    const uint32_t n = 1u << lg;
+    for (int kv = 0; kv < 2; ++kv) {
+      VrdxSorterStorageRequirements req;
+      if (kv)
+        vrdxGetSorterKeyValueStorageRequirements(h.sorter, n, &req);
+      else
+        vrdxGetSorterStorageRequirements(h.sorter, n, &req);
+      const uint32_t inout = Align16(n * 4u);
+      h.reserve((size_t)2 * inout + 16, (size_t)req.size);
+      std::vector<uint64_t> gpu, wall, stage[5];
+      for (int runIdx = 0; runIdx < 11; ++runIdx) {  // 1 warm-up + 10 timed, fresh data each run
+        std::vector<uint32_t> v;
+        auto k = Mt(n, runIdx + 1, 32, &v);
+        HIP_OK(hipMemcpy(h.dKeys, k.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(h.dKeys + inout, v.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipDeviceSynchronize());
+        const auto t0 = std::chrono::steady_clock::now();
+        if (kv)
+          vrdxCmdSortKeyValue((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dKeys, inout,
+                              (VkBuffer)h.dStorage, 0, h.pool, 0);
+        else
+          vrdxCmdSort((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dStorage, 0, h.pool, 0);
+        HIP_OK(hipStreamSynchronize(h.stream));
+        const auto t1 = std::chrono::steady_clock::now();
+        uint64_t ts[15];
+        if (vrdxHipGetQueryPoolResults(h.pool, 0, 15, ts) != VK_SUCCESS) std::exit(3);
+        if (runIdx == 0) continue;
+        gpu.push_back(ts[14]);
+        wall.push_back((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count());
+        stage[0].push_back(ts[2] - ts[1]);
+        for (int p = 0; p < 4; ++p) stage[1 + p].push_back(ts[4 + 3 * p] - ts[3 + 3 * p]);
+      }
+      const double ms = Median(gpu) / 1e6;
+      const double bytes = (kv ? 68.0 : 36.0) * n;  // algorithmic bytes, SURVEY.md section 8(d)
+      const double gbps = bytes / (ms * 1e-3) / 1e9;
+      std::printf("%-10u %-6s %10.4f %10.4f %12.3f %10.1f %7.1f%%   %.4f | %.4f %.4f %.4f %.4f\n", n,
+                  kv ? "kv" : "keys", ms, Median(wall) / 1e6, n / (ms * 1e-3) / 1e9, gbps, 100.0 * gbps / 8000.0,
+                  Median(stage[0]) / 1e6, Median(stage[1]) / 1e6, Median(stage[2]) / 1e6, Median(stage[3]) / 1e6,
+                  Median(stage[4]) / 1e6);
+      std::fflush(stdout);
+    }
+  }
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  const std::string what = argc > 1 ? argv[1] : "parity";
+  Harness h;
+  h.init();
+  std::printf("%s\n", vrdxHipVersionString());
+  if (what == "parity" || what == "quick") return Parity(h, what == "quick") ? 1 : 0;
+  if (what == "bench") {
+    std::vector<int> logs;
+    for (int i = 2; i < argc; ++i) logs.push_back(std::atoi(argv[i]));
+    if (logs.empty()) logs = {18, 20, 22, 24, 25};
+    Bench(h, logs);
+    return 0;
+  }
+  std::fprintf(stderr, "usage: %s parity|quick|bench [log2n...]\n", argv[0]);
+  return 64;
+}

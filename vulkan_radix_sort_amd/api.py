@@ -1,0 +1,248 @@
+"""ctypes binding of libvrdx_hip.so -- the eight vrdx* entry points of include/vk_radix_sort.h.
+
+Mirrors the reference interface (src/vk_radix_sort.h.in:11-81 under /root/reference):
+
+=============================================  ==============================================
+reference (C++ / Vulkan)                        here
+=============================================  ==============================================
+``vrdxCreateSorter(&info, &sorter)``            ``Sorter(device=None)`` (raises ``VrdxError``)
+``vrdxDestroySorter(sorter)``                   ``Sorter.destroy()`` / context manager
+``vrdxGetSorterStorageRequirements``            ``Sorter.storage_requirements(n)``
+``vrdxGetSorterKeyValueStorageRequirements``    ``Sorter.key_value_storage_requirements(n)``
+``vrdxCmdSort``                                 ``Sorter.cmd_sort(stream, n, keys, keys_off, storage, storage_off, pool, query)``
+``vrdxCmdSortIndirect``                         ``Sorter.cmd_sort_indirect(...)``
+``vrdxCmdSortKeyValue``                         ``Sorter.cmd_sort_key_value(...)``
+``vrdxCmdSortKeyValueIndirect``                 ``Sorter.cmd_sort_key_value_indirect(...)``
+=============================================  ==============================================
+
+``VkCommandBuffer`` is a ``hipStream_t`` (an ``int`` handle, e.g. ``torch.cuda.current_stream().cuda_stream``),
+``VkBuffer`` is a device address (``tensor.data_ptr()``), offsets are bytes.  Like the reference,
+the ``cmd_*`` calls validate nothing and never block the host.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+VK_SUCCESS = 0
+VK_NOT_READY = 1
+VK_ERROR_OUT_OF_HOST_MEMORY = -1
+VK_ERROR_INITIALIZATION_FAILED = -3
+VK_ERROR_FEATURE_NOT_PRESENT = -8
+
+# VK_BUFFER_USAGE_STORAGE_BUFFER_BIT | VK_BUFFER_USAGE_TRANSFER_DST_BIT
+STORAGE_USAGE = 0x20 | 0x02
+
+EXPORTED_SYMBOLS = (
+    # the reference's eight entry points (src/vk_radix_sort.h.in:24-81)
+    "vrdxCreateSorter",
+    "vrdxDestroySorter",
+    "vrdxGetSorterStorageRequirements",
+    "vrdxGetSorterKeyValueStorageRequirements",
+    "vrdxCmdSort",
+    "vrdxCmdSortIndirect",
+    "vrdxCmdSortKeyValue",
+    "vrdxCmdSortKeyValueIndirect",
+    # HIP companions of the Vulkan objects callers create themselves
+    "vrdxHipCreateQueryPool",
+    "vrdxHipDestroyQueryPool",
+    "vrdxHipGetQueryPoolResults",
+    "vrdxHipReadStatus",
+    "vrdxHipVersionString",
+)
+
+
+class VrdxError(RuntimeError):
+    """A vrdx* call returned a VkResult other than VK_SUCCESS."""
+
+    def __init__(self, what: str, result: int):
+        super().__init__(f"{what} failed with VkResult {result}")
+        self.result = result
+
+
+class VrdxSorterCreateInfo(ctypes.Structure):
+    # src/vk_radix_sort.h.in:18-22
+    _fields_ = [("physicalDevice", ctypes.c_void_p), ("device", ctypes.c_void_p),
+                ("pipelineCache", ctypes.c_void_p)]
+
+
+class VrdxSorterStorageRequirements(ctypes.Structure):
+    # src/vk_radix_sort.h.in:28-31
+    _fields_ = [("size", ctypes.c_uint64), ("usage", ctypes.c_uint32)]
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvrdx_hip.so")
+
+
+_LIB: Optional[ctypes.CDLL] = None
+
+
+def load_library() -> ctypes.CDLL:
+    """Loads libvrdx_hip.so.  There is deliberately no fallback of any kind."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: build it with `make -C vulkan_radix_sort_amd/csrc` "
+            "(or __graft_entry__.build()).  There is no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    vp, u32, u64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64
+    lib.vrdxCreateSorter.restype = ctypes.c_int32
+    lib.vrdxCreateSorter.argtypes = [ctypes.POINTER(VrdxSorterCreateInfo), ctypes.POINTER(vp)]
+    lib.vrdxDestroySorter.restype = None
+    lib.vrdxDestroySorter.argtypes = [vp]
+    for name in ("vrdxGetSorterStorageRequirements", "vrdxGetSorterKeyValueStorageRequirements"):
+        fn = getattr(lib, name)
+        fn.restype = None
+        fn.argtypes = [vp, u32, ctypes.POINTER(VrdxSorterStorageRequirements)]
+    lib.vrdxCmdSort.restype = None
+    lib.vrdxCmdSort.argtypes = [vp, vp, u32, vp, u64, vp, u64, vp, u32]
+    lib.vrdxCmdSortIndirect.restype = None
+    lib.vrdxCmdSortIndirect.argtypes = [vp, vp, u32, vp, u64, vp, u64, vp, u64, vp, u32]
+    lib.vrdxCmdSortKeyValue.restype = None
+    lib.vrdxCmdSortKeyValue.argtypes = [vp, vp, u32, vp, u64, vp, u64, vp, u64, vp, u32]
+    lib.vrdxCmdSortKeyValueIndirect.restype = None
+    lib.vrdxCmdSortKeyValueIndirect.argtypes = [vp, vp, u32, vp, u64, vp, u64, vp, u64, vp, u64, vp, u32]
+    lib.vrdxHipCreateQueryPool.restype = ctypes.c_int32
+    lib.vrdxHipCreateQueryPool.argtypes = [u32, ctypes.POINTER(vp)]
+    lib.vrdxHipDestroyQueryPool.restype = None
+    lib.vrdxHipDestroyQueryPool.argtypes = [vp]
+    lib.vrdxHipGetQueryPoolResults.restype = ctypes.c_int32
+    lib.vrdxHipGetQueryPoolResults.argtypes = [vp, u32, u32, ctypes.POINTER(u64)]
+    lib.vrdxHipReadStatus.restype = u32
+    lib.vrdxHipReadStatus.argtypes = [vp, vp, u64]
+    lib.vrdxHipVersionString.restype = ctypes.c_char_p
+    lib.vrdxHipVersionString.argtypes = []
+    _LIB = lib
+    return lib
+
+
+def version_string() -> str:
+    return load_library().vrdxHipVersionString().decode()
+
+
+def _handle(x) -> Optional[int]:
+    if x is None:
+        return None
+    return int(x) or None
+
+
+class QueryPool:
+    """HIP stand-in for a VkQueryPool of timestamp queries (hipEvent_t per slot)."""
+
+    def __init__(self, count: int = 15):
+        self._lib = load_library()
+        h = ctypes.c_void_p()
+        r = self._lib.vrdxHipCreateQueryPool(count, ctypes.byref(h))
+        if r != VK_SUCCESS:
+            raise VrdxError("vrdxHipCreateQueryPool", r)
+        self.handle = h.value
+        self.count = count
+
+    def results_ns(self, first: int = 0, count: Optional[int] = None):
+        """vkGetQueryPoolResults analogue: ns since slot `first` for each slot (stream must be done)."""
+        count = self.count - first if count is None else count
+        data = (ctypes.c_uint64 * count)()
+        r = self._lib.vrdxHipGetQueryPoolResults(self.handle, first, count, data)
+        if r != VK_SUCCESS:
+            raise VrdxError("vrdxHipGetQueryPoolResults", r)
+        return [int(x) for x in data]
+
+    def destroy(self):
+        if self.handle:
+            self._lib.vrdxHipDestroyQueryPool(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class Sorter:
+    """VrdxSorter.  ``device`` is a HIP ordinal, or None for the current device."""
+
+    def __init__(self, device: Optional[int] = None):
+        self._lib = load_library()
+        info = VrdxSorterCreateInfo()
+        encoded = None if device is None else device + 1  # VRDX_HIP_DEVICE(ordinal)
+        info.physicalDevice = encoded
+        info.device = encoded
+        info.pipelineCache = None
+        h = ctypes.c_void_p()
+        r = self._lib.vrdxCreateSorter(ctypes.byref(info), ctypes.byref(h))
+        if r != VK_SUCCESS:
+            raise VrdxError("vrdxCreateSorter", r)
+        self.handle = h.value
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def destroy(self):
+        if getattr(self, "handle", None):
+            self._lib.vrdxDestroySorter(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.destroy()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    # -- storage ----------------------------------------------------------------------------
+    def storage_requirements(self, max_element_count: int) -> VrdxSorterStorageRequirements:
+        req = VrdxSorterStorageRequirements()
+        self._lib.vrdxGetSorterStorageRequirements(self.handle, max_element_count, ctypes.byref(req))
+        return req
+
+    def key_value_storage_requirements(self, max_element_count: int) -> VrdxSorterStorageRequirements:
+        req = VrdxSorterStorageRequirements()
+        self._lib.vrdxGetSorterKeyValueStorageRequirements(self.handle, max_element_count, ctypes.byref(req))
+        return req
+
+    # -- recording --------------------------------------------------------------------------
+    def cmd_sort(self, command_buffer, element_count, keys, keys_offset, storage, storage_offset,
+                 query_pool=None, query=0):
+        self._lib.vrdxCmdSort(_handle(command_buffer), self.handle, element_count, _handle(keys), keys_offset,
+                              _handle(storage), storage_offset, _pool(query_pool), query)
+
+    def cmd_sort_indirect(self, command_buffer, max_element_count, indirect, indirect_offset, keys,
+                          keys_offset, storage, storage_offset, query_pool=None, query=0):
+        self._lib.vrdxCmdSortIndirect(_handle(command_buffer), self.handle, max_element_count,
+                                      _handle(indirect), indirect_offset, _handle(keys), keys_offset,
+                                      _handle(storage), storage_offset, _pool(query_pool), query)
+
+    def cmd_sort_key_value(self, command_buffer, element_count, keys, keys_offset, values, values_offset,
+                           storage, storage_offset, query_pool=None, query=0):
+        self._lib.vrdxCmdSortKeyValue(_handle(command_buffer), self.handle, element_count, _handle(keys),
+                                      keys_offset, _handle(values), values_offset, _handle(storage),
+                                      storage_offset, _pool(query_pool), query)
+
+    def cmd_sort_key_value_indirect(self, command_buffer, max_element_count, indirect, indirect_offset,
+                                    keys, keys_offset, values, values_offset, storage, storage_offset,
+                                    query_pool=None, query=0):
+        self._lib.vrdxCmdSortKeyValueIndirect(_handle(command_buffer), self.handle, max_element_count,
+                                              _handle(indirect), indirect_offset, _handle(keys), keys_offset,
+                                              _handle(values), values_offset, _handle(storage),
+                                              storage_offset, _pool(query_pool), query)
+
+    # -- diagnostics ------------------------------------------------------------------------
+    def read_status(self, command_buffer, storage, storage_offset=0) -> int:
+        return int(self._lib.vrdxHipReadStatus(_handle(command_buffer), _handle(storage), storage_offset))
+
+
+def _pool(p) -> Optional[int]:
+    if p is None:
+        return None
+    if isinstance(p, QueryPool):
+        return p.handle
+    return _handle(p)

@@ -1,0 +1,52 @@
+// Launch interface between the host recorder (vrdx_api.cpp) and the device kernels
+// (vrdx_kernels.hip).  Plain pointers and integers only.
+#ifndef VRDX_KERNELS_H
+#define VRDX_KERNELS_H
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace vrdx {
+
+constexpr uint32_t kHistThreads = 1024;
+constexpr uint32_t kHistCopies = 8;
+// keys one histogram workgroup handles per loop trip (kHistThreads lanes x 4 uint4 x 4 keys)
+constexpr uint32_t kHistKeysPerTrip = kHistThreads * 4 * 4;
+
+struct TileConfig {
+  int threads;
+  int keysPerThread;
+  uint32_t tileKeys() const { return (uint32_t)threads * (uint32_t)keysPerThread; }
+};
+constexpr int kNumTileConfigs = 5;
+extern const TileConfig kTileConfigs[kNumTileConfigs];
+
+struct OnesweepArgs {
+  const uint32_t* keysIn;
+  uint32_t* keysOut;
+  const uint32_t* valuesIn;   // KV only
+  uint32_t* valuesOut;        // KV only
+  uint32_t maxCount;          // element count (direct) or upper bound (indirect)
+  const uint32_t* countPtr;   // device-side element count (indirect) or nullptr
+  const uint32_t* globalHistogram;  // this pass's 256 raw digit counts
+  uint32_t* statusCur;        // status region of this pass: [statusRows][256]
+  uint32_t* statusNext;       // region to clear for the next pass, or nullptr on the last pass
+  uint32_t statusRows;
+  uint32_t* ticketCur;
+  uint32_t* ticketNext;
+  uint32_t* failure;
+  uint32_t shift;             // 8 * pass
+};
+
+// Raises the dynamic-LDS limit of both instantiations (keys-only, key-value) of one tile config.
+hipError_t PrepareKernels(int configIndex);
+
+void LaunchHistogram(hipStream_t stream, uint32_t grid, const uint32_t* keys, uint32_t maxCount,
+                     const uint32_t* countPtr, uint32_t* globalHistogram);
+
+void LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool keyValue,
+                    const OnesweepArgs& args);
+
+}  // namespace vrdx
+
+#endif  // VRDX_KERNELS_H

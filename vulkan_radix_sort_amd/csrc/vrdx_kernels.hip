@@ -1,0 +1,420 @@
+// Device kernels of the MI355X (gfx950, wave64) 32-bit LSD radix sort behind vrdxCmdSort*.
+//
+// What the reference computes on this path (and what these kernels must reproduce bit for bit):
+//   4 passes x 8-bit digits, each pass a stable counting sort of the keys (and values) by digit
+//   `pass` -- src/shader/upsweep.slang:10-45 (per-partition digit histogram + global histogram),
+//   src/shader/spine.slang:11-84 (exclusive scan over partitions and over digits) and
+//   src/shader/downsweep.slang:41-224 (stable rank inside the partition + scatter).
+//
+// How it is done here (not a translation of those shaders):
+//   * histogram_kernel  -- ONE coalesced 16 B/lane read of the keys builds all four 256-bin digit
+//     histograms (the reference re-reads the keys once per pass) into the same uint[4][256] table
+//     the reference calls globalHistogram (src/vk_radix_sort.h.in:405-406).
+//   * onesweep_kernel   -- one launch per pass fuses upsweep + spine + downsweep: a tile of
+//     THREADS*KPT keys is ranked with wave64 match-any ballots, publishes its 256 digit counts as
+//     {flag,value} status words, resolves its global offsets with a decoupled look-back over the
+//     preceding tiles (agent-scope relaxed atomics: the 8 XCD L2s are not coherent), regroups keys
+//     by digit in LDS and writes them out with consecutive lanes on consecutive addresses.
+//   Tile ids are handed out by an atomic ticket in ARRIVAL order, so a look-back only ever waits
+//   on a tile that is already running; every spin is bounded (failure word, never a hang).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vrdx_kernels.h"
+#include "vrdx_layout.h"
+
+namespace vrdx {
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+
+// Tile status words cross CUs and XCDs inside one launch: every access is a relaxed agent-scope
+// atomic (global_load/store ... sc1).  The word carries its own flag, so no fence is needed
+// (the "data is the flag" granule form).
+__device__ __forceinline__ uint32_t LoadStatus(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void StoreStatus(uint32_t* p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint32_t ElementCount(uint32_t maxCount, const uint32_t* countPtr) {
+  if (countPtr == nullptr) return maxCount;
+  const uint32_t c = *countPtr;
+  return c < maxCount ? c : maxCount;
+}
+
+// Lanes of this wave whose 8-bit digit equals mine (all 64 lanes must be active).
+// 8 ballots; for each bit keep the lanes that agree with my bit.
+__device__ __forceinline__ uint64_t MatchDigit(uint32_t digit) {
+  uint64_t mask = ~0ull;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const bool bit = (digit >> b) & 1u;
+    const uint64_t ballot = __ballot(bit);
+    mask &= bit ? ballot : ~ballot;
+  }
+  return mask;
+}
+
+__device__ __forceinline__ uint32_t LanesBelow(uint64_t mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                   __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Exclusive scan of one value per thread over threads 0..255 (4 waves); other threads pass 0 and
+// ignore the result.  Contains one __syncthreads(): every thread of the block must call it.
+__device__ __forceinline__ uint32_t BlockExclusiveScan256(uint32_t v, uint32_t* scratch4, int tid) {
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(x, o);
+    if (lane >= o) x += y;
+  }
+  if (wave < 4 && lane == 63) scratch4[wave] = x;
+  __syncthreads();
+  uint32_t add = 0;
+  if (wave < 4) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+      if (w < wave) add += scratch4[w];
+  }
+  return x - v + add;
+}
+
+// ---------------------------------------------------------------------------------------------
+// histogram: all four digit histograms in one pass over the keys
+// ---------------------------------------------------------------------------------------------
+// LDS counters are replicated HIST_COPIES times (copy = lane % HIST_COPIES, copies of one bin in
+// consecutive banks) so that all-equal / few-distinct keys do not serialise on one LDS address
+// the way the reference's 512-way atomicAdd on localHistogram[radix] does (upsweep.slang:34).
+
+__global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t* __restrict__ keys,
+                                                                  uint32_t maxCount,
+                                                                  const uint32_t* countPtr,
+                                                                  uint32_t* __restrict__ globalHistogram) {
+  __shared__ uint32_t bins[VRDX_PASSES * VRDX_RADIX * kHistCopies];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t n = ElementCount(maxCount, countPtr);
+
+  for (uint32_t i = tid; i < VRDX_PASSES * VRDX_RADIX * kHistCopies; i += kHistThreads) bins[i] = 0;
+  __syncthreads();
+
+  const uint32_t copy = tid & (kHistCopies - 1);
+  auto count = [&](uint32_t key) {
+#pragma unroll
+    for (uint32_t p = 0; p < VRDX_PASSES; ++p) {
+      const uint32_t d = (key >> (8 * p)) & 0xFFu;
+      atomicAdd(&bins[(p * VRDX_RADIX + d) * kHistCopies + copy], 1u);
+    }
+  };
+
+  const uint32_t nvec = n >> 2;
+  const uint4* keys4 = reinterpret_cast<const uint4*>(keys);
+  constexpr uint32_t kUnroll = 4;
+  const uint32_t chunk = kHistThreads * kUnroll;
+  for (uint32_t base = blockIdx.x * chunk; base < nvec; base += gridDim.x * chunk) {
+    uint4 k[kUnroll];
+#pragma unroll
+    for (uint32_t u = 0; u < kUnroll; ++u) {
+      const uint32_t i = base + u * kHistThreads + tid;
+      k[u] = i < nvec ? keys4[i] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < kUnroll; ++u) {
+      const uint32_t i = base + u * kHistThreads + tid;
+      if (i < nvec) {
+        count(k[u].x);
+        count(k[u].y);
+        count(k[u].z);
+        count(k[u].w);
+      }
+    }
+  }
+  if (blockIdx.x == 0 && tid < (n & 3u)) count(keys[(nvec << 2) + tid]);
+  __syncthreads();
+
+  for (uint32_t b = tid; b < VRDX_PASSES * VRDX_RADIX; b += kHistThreads) {
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < kHistCopies; ++c) sum += bins[b * kHistCopies + c];
+    if (sum != 0) atomicAdd(&globalHistogram[b], sum);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// onesweep: rank + decoupled look-back + scatter, one launch per pass
+// ---------------------------------------------------------------------------------------------
+
+// Thread `digit` of tile `tile` sums the counts of the preceding tiles until it meets an inclusive
+// prefix.  kWindow status words are requested per trip so that their latencies overlap.
+__device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t tile, uint32_t digit,
+                                             uint32_t* failure) {
+  constexpr int kWindow = 4;
+  constexpr uint32_t kSpinLimit = 1u << 20;
+  uint32_t exclusive = 0;
+  int32_t j = (int32_t)tile - 1;
+  uint32_t spins = 0;
+  bool done = false;
+  while (!done) {
+    uint32_t v[kWindow];
+#pragma unroll
+    for (int k = 0; k < kWindow; ++k) {
+      const int32_t jj = j - k;
+      v[k] = jj >= 0 ? LoadStatus(&status[(uint32_t)jj * VRDX_RADIX + digit])
+                     : (VRDX_FLAG_INCLUSIVE << VRDX_FLAG_SHIFT);
+    }
+    bool open = true;
+    int consumed = 0;
+#pragma unroll
+    for (int k = 0; k < kWindow; ++k) {
+      const uint32_t flag = v[k] >> VRDX_FLAG_SHIFT;
+      if (open && flag != VRDX_FLAG_EMPTY) {
+        exclusive += v[k] & VRDX_VALUE_MASK;
+        ++consumed;
+        if (flag == VRDX_FLAG_INCLUSIVE) {
+          done = true;
+          open = false;
+        }
+      } else {
+        open = false;
+      }
+    }
+    j -= consumed;
+    if (!done && consumed == 0) {
+      if (++spins > kSpinLimit) {
+        atomicOr(failure, 1u);
+        done = true;
+      } else {
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+  }
+  return exclusive;
+}
+
+template <int THREADS, int KPT, bool KV>
+__global__ __launch_bounds__(THREADS) void onesweep_kernel(OnesweepArgs a) {
+  constexpr int WAVES = THREADS / 64;
+  constexpr uint32_t TILE = THREADS * KPT;
+  static_assert(THREADS >= 256 && THREADS % 64 == 0, "one thread per digit for the tile scan");
+
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  uint32_t* const sorted = smem;                          // TILE words: keys (then values) regrouped by digit
+  uint32_t* const waveHist = smem + TILE;                 // WAVES x 256
+  uint32_t* const tileOffset = waveHist + WAVES * 256;    // 256: global base - tile-local base, per digit
+  uint32_t* const scanScratch = tileOffset + 256;         // 8
+  uint32_t* const misc = scanScratch + 8;                 // [0] ticket
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+
+  if (tid == 0) misc[0] = atomicAdd(a.ticketCur, 1u);
+  for (int i = tid; i < WAVES * 256; i += THREADS) waveHist[i] = 0;
+  __syncthreads();
+
+  const uint32_t tile = misc[0];
+  const uint32_t n = ElementCount(a.maxCount, a.countPtr);
+  const uint32_t tiles = (n + TILE - 1) / TILE;
+  if (tile >= tiles) return;  // uniform for the whole workgroup
+  const bool lastTile = tile == tiles - 1;
+  const uint32_t tileStart = tile * TILE;
+  const uint32_t valid = (n - tileStart) < TILE ? (n - tileStart) : TILE;
+
+  // Housekeeping for the NEXT pass (its kernel starts after this one has drained): clear my row
+  // of the other status region and the other ticket.
+  if (a.statusNext != nullptr) {
+    if (tid < 256 && tile < a.statusRows) a.statusNext[tile * VRDX_RADIX + tid] = 0;
+    if (tile == 0 && tid == 0) *a.ticketNext = 0;
+  }
+
+  // ---- load: wave-striped, so that (slot, lane) order == memory order inside a wave ----------
+  uint32_t key[KPT];
+  uint32_t val[KV ? KPT : 1];
+  {
+    const uint32_t base = tileStart + wave * (KPT * 64) + lane;
+    if (valid == TILE) {
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) key[i] = a.keysIn[base + i * 64];
+      if (KV) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) val[i] = a.valuesIn[base + i * 64];
+      }
+    } else {
+      // Ragged last tile: pad with 0xFFFFFFFF like the reference (downsweep.slang:81).  Pads sit
+      // at the highest memory positions of the tile and have digit 255 in every pass, so the
+      // stable ranking puts them at tile-local positions >= valid, where nothing is written.
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        const uint32_t idx = base + i * 64;
+        key[i] = idx < n ? a.keysIn[idx] : 0xFFFFFFFFu;
+      }
+      if (KV) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+          const uint32_t idx = base + i * 64;
+          val[i] = idx < n ? a.valuesIn[idx] : 0u;
+        }
+      }
+    }
+  }
+
+  // ---- rank inside the wave: match-any ballots + a wave-private running digit counter ---------
+  // rank = (#same-digit keys of this wave in earlier slots) + (#same-digit lower lanes).  The
+  // counter read and the leader's add are issued back to back (the add does not depend on the
+  // read); LDS executes a wave's operations in order, so slot i+1 sees slot i's add.
+  uint32_t rank[KPT];
+  {
+    uint32_t* const myHist = waveHist + wave * 256;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const uint32_t d = (key[i] >> a.shift) & 0xFFu;
+      const uint64_t same = MatchDigit(d);
+      const uint32_t below = LanesBelow(same);
+      const uint32_t prior = __hip_atomic_load(&myHist[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (below == 0)
+        __hip_atomic_fetch_add(&myHist[d], (uint32_t)__popcll(same), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+      rank[i] = prior + below;
+    }
+  }
+  __syncthreads();
+
+  // ---- tile histogram, aggregate publish, tile-local digit offsets ---------------------------
+  uint32_t count = 0;
+  if (tid < 256) {
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) count += waveHist[w * 256 + tid];
+    // Tile 0 never publishes a bare aggregate: its inclusive value carries the global digit base.
+    if (tile != 0 && !lastTile)
+      StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid], (VRDX_FLAG_AGGREGATE << VRDX_FLAG_SHIFT) | count);
+  }
+  const uint32_t tileExclusive = BlockExclusiveScan256(tid < 256 ? count : 0u, scanScratch, tid);
+  uint32_t globalExclusive = 0;
+  if (tile == 0) {
+    // spine.slang:62-83 equivalent: exclusive scan of this pass's 256 global digit counts.
+    const uint32_t g = tid < 256 ? a.globalHistogram[tid] : 0u;
+    globalExclusive = BlockExclusiveScan256(g, scanScratch + 4, tid);
+  }
+  if (tid < 256) {
+    uint32_t run = tileExclusive;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+      const uint32_t c = waveHist[w * 256 + tid];
+      waveHist[w * 256 + tid] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+
+  // ---- decoupled look-back (threads 0..255, one digit each) while the other waves regroup -----
+  if (tid < 256) {
+    const uint32_t exclusive = tile == 0 ? globalExclusive : LookBack(a.statusCur, tile, tid, a.failure);
+    if (!lastTile)
+      StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid],
+                  (VRDX_FLAG_INCLUSIVE << VRDX_FLAG_SHIFT) | ((exclusive + count) & VRDX_VALUE_MASK));
+    tileOffset[tid] = exclusive - tileExclusive;
+  }
+
+  // ---- regroup keys by digit in LDS ----------------------------------------------------------
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) {
+    const uint32_t d = (key[i] >> a.shift) & 0xFFu;
+    rank[i] += waveHist[wave * 256 + d];  // now the tile-local sorted position
+    sorted[rank[i]] = key[i];
+  }
+  __syncthreads();
+
+  // ---- scatter: consecutive lanes -> consecutive addresses inside each digit run --------------
+  uint32_t dst[KV ? KPT : 1];
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const uint32_t p = tid + j * THREADS;
+    if (p < valid) {
+      const uint32_t k = sorted[p];
+      const uint32_t d = (k >> a.shift) & 0xFFu;
+      const uint32_t o = tileOffset[d] + p;
+      a.keysOut[o] = k;
+      if (KV) dst[j] = o;
+    }
+  }
+
+  if (KV) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) sorted[rank[i]] = val[i];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const uint32_t p = tid + j * THREADS;
+      if (p < valid) a.valuesOut[dst[j]] = sorted[p];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------
+
+template <int THREADS, int KPT>
+static size_t OnesweepLdsBytes() {
+  return ((size_t)THREADS * KPT + (THREADS / 64) * 256 + 256 + 8 + 4) * sizeof(uint32_t);
+}
+
+template <int THREADS, int KPT>
+static hipError_t PrepareConfig() {
+  const int bytes = (int)OnesweepLdsBytes<THREADS, KPT>();
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+template <int THREADS, int KPT>
+static void LaunchConfig(hipStream_t stream, uint32_t grid, bool keyValue, const OnesweepArgs& args) {
+  const size_t lds = OnesweepLdsBytes<THREADS, KPT>();
+  if (keyValue)
+    hipLaunchKernelGGL((onesweep_kernel<THREADS, KPT, true>), dim3(grid), dim3(THREADS), lds, stream, args);
+  else
+    hipLaunchKernelGGL((onesweep_kernel<THREADS, KPT, false>), dim3(grid), dim3(THREADS), lds, stream, args);
+}
+
+const TileConfig kTileConfigs[kNumTileConfigs] = {
+    {512, 16}, {1024, 16}, {512, 32}, {1024, 8}, {256, 32},
+};
+
+hipError_t PrepareKernels(int configIndex) {
+  switch (configIndex) {
+    case 0: return PrepareConfig<512, 16>();
+    case 1: return PrepareConfig<1024, 16>();
+    case 2: return PrepareConfig<512, 32>();
+    case 3: return PrepareConfig<1024, 8>();
+    case 4: return PrepareConfig<256, 32>();
+    default: return hipErrorInvalidValue;
+  }
+}
+
+void LaunchHistogram(hipStream_t stream, uint32_t grid, const uint32_t* keys, uint32_t maxCount,
+                     const uint32_t* countPtr, uint32_t* globalHistogram) {
+  hipLaunchKernelGGL(histogram_kernel, dim3(grid), dim3(kHistThreads), 0, stream, keys, maxCount, countPtr,
+                     globalHistogram);
+}
+
+void LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool keyValue,
+                    const OnesweepArgs& args) {
+  switch (configIndex) {
+    case 0: LaunchConfig<512, 16>(stream, grid, keyValue, args); break;
+    case 1: LaunchConfig<1024, 16>(stream, grid, keyValue, args); break;
+    case 2: LaunchConfig<512, 32>(stream, grid, keyValue, args); break;
+    case 3: LaunchConfig<1024, 8>(stream, grid, keyValue, args); break;
+    case 4: LaunchConfig<256, 32>(stream, grid, keyValue, args); break;
+    default: break;
+  }
+}
+
+}  // namespace vrdx
