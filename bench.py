@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the vrdxCmdSort* hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log2n 25]
+
+A "step" is one complete sort (histogram + 4 onesweep passes) of one batch of synthetic input:
+N = 2^25 uniform-random u32 keys (BASELINE.json configs[1]); the key+value figure (configs[2]) is
+measured the same way and reported in the same JSON line under "key_value".  Inputs are resident
+in HBM before the timed region starts: every step sorts its own pre-generated array in place, so
+the timed region holds exactly K sorts and nothing else (the reference likewise excludes upload
+and read-back: bench/vulkan_benchmark.cc:267-290,306-316, and uses fresh data per run:
+bench/bench.cc:83-84).
+
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) this is the batched
+many-arrays variant: every rank sorts its own independent arrays, there is no collective on the
+data path, and value = items sorted by all ranks / max-over-ranks time ("scaling": "weak").
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290
+KEYS_BYTES_PER_ITEM = 36.0   # 4 (fused histogram read) + 4 passes x (4 read + 4 write)
+KV_BYTES_PER_ITEM = 68.0     # 4 + 4 x (8 + 8)
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)    # bench/bench.cc:16 kTimedRuns
+    p.add_argument("--warmup", type=int, default=1)    # bench/bench.cc:15 kWarmupRuns
+    p.add_argument("--log2n", type=int, default=25)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    return p.parse_args()
+
+
+def random_u32(torch, n, seed, device):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    # uniform over the full 32-bit range, stored as int32 bit patterns
+    return torch.randint(-(1 << 31), 1 << 31, (n,), generator=g, device=device, dtype=torch.int64).to(torch.int32)
+
+
+def timed_sorts(torch, dist, sorter, n, steps, warmup, key_value, device, distributed):
+    """Returns (wall_seconds_for_K_steps_max_over_ranks, per-step gpu ms list of this rank)."""
+    stream = torch.cuda.current_stream().cuda_stream
+    req = sorter.key_value_storage_requirements(n) if key_value else sorter.storage_requirements(n)
+    storage = torch.empty(req.size, dtype=torch.uint8, device=device)
+    total = steps + warmup
+    seed0 = 1000 * (int(os.environ.get("RANK", "0")) + 1)
+    keys = [random_u32(torch, n, seed0 + i, device) for i in range(total)]
+    values = [random_u32(torch, n, seed0 + 500 + i, device) for i in range(total)] if key_value else None
+
+    def one(i):
+        if key_value:
+            sorter.cmd_sort_key_value(stream, n, keys[i].data_ptr(), 0, values[i].data_ptr(), 0,
+                                      storage.data_ptr(), 0)
+        else:
+            sorter.cmd_sort(stream, n, keys[i].data_ptr(), 0, storage.data_ptr(), 0)
+
+    for i in range(warmup):
+        one(i)
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        starts[s].record()
+        one(warmup + s)
+        ends[s].record()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    per_step_ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]
+    status = sorter.read_status(stream, storage.data_ptr(), 0)
+    if status != 0:
+        raise RuntimeError(f"device failure word {status}: look-back spin expired")
+    # the last step's output must be sorted (cheap sanity check outside the timed region)
+    k = keys[-1].view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    if not bool((k[1:] >= k[:-1]).all()):
+        raise RuntimeError("output not sorted")
+    del keys, values, storage
+    torch.cuda.empty_cache()
+    return elapsed, per_step_ms
+
+
+def stage_profile(torch, sorter, n, key_value, device, repeats=5):
+    """Per-kernel durations from the 15-slot timestamp contract (HIP events on the sort's own
+    stream): returns (histogram_ms, mean onesweep launch ms)."""
+    import vulkan_radix_sort_amd as vrdx
+    stream = torch.cuda.current_stream().cuda_stream
+    req = sorter.key_value_storage_requirements(n) if key_value else sorter.storage_requirements(n)
+    storage = torch.empty(req.size, dtype=torch.uint8, device=device)
+    pool = vrdx.QueryPool(15)
+    hist, sweep = [], []
+    for r in range(repeats + 1):
+        keys = random_u32(torch, n, 77 + r, device)
+        values = random_u32(torch, n, 177 + r, device) if key_value else None
+        torch.cuda.synchronize()
+        if key_value:
+            sorter.cmd_sort_key_value(stream, n, keys.data_ptr(), 0, values.data_ptr(), 0, storage.data_ptr(), 0,
+                                      pool, 0)
+        else:
+            sorter.cmd_sort(stream, n, keys.data_ptr(), 0, storage.data_ptr(), 0, pool, 0)
+        torch.cuda.synchronize()
+        ts = pool.results_ns()
+        if r == 0:
+            continue
+        hist.append((ts[2] - ts[1]) / 1e6)
+        sweep += [(ts[4 + 3 * p] - ts[3 + 3 * p]) / 1e6 for p in range(4)]
+    pool.destroy()
+    return sum(hist) / len(hist), sum(sweep) / len(sweep)
+
+
+def cpu_baseline(n):
+    """The reference's CPU path (bench/cpu_benchmark.cc: std::sort / std::stable_sort, 1 thread)
+    timed on this box's host cores on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import load_oracle, load_reference
+    orc = load_oracle()
+    ref = load_reference()
+    keys, values = orc.generate(1, n, 32)
+    if ref is not None:
+        kind = "reference"
+        _, ns_keys = ref.sort_keys(keys)
+        _, _, ns_kv = ref.sort_key_value(keys, values)
+    else:
+        kind = "port"
+        _, ns_keys = orc.port_sort_keys(keys)
+        _, _, ns_kv = orc.port_sort_key_value(keys, values)
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {
+        "value": n / ns_keys, "unit": "GItems/s", "cores": 1, "kind": kind,
+        "sample": f"1 run of N=2^{n.bit_length() - 1} mt19937 u32: keys-only std::sort {ns_keys / 1e6:.0f} ms, "
+                  f"key+value std::stable_sort(index) {ns_kv / 1e6:.0f} ms (timed like bench/cpu_benchmark.cc:22-25,38-41)",
+        "key_value_value": n / ns_kv, "host_cpu": model, "host_threads_available": os.cpu_count(),
+    }
+
+
+def latest_pmc_traffic():
+    """HBM bytes per onesweep launch from the rocprofv3 PMC passes committed under profiles/
+    (collected offline: PMC cannot be read from inside this process)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    import vulkan_radix_sort_amd as vrdx
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    n_gpus = world if distributed else 1
+    if args.gpus != n_gpus and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run; "
+              f"measuring {n_gpus} GPU(s)", file=sys.stderr)
+
+    n = 1 << args.log2n
+    sorter = vrdx.Sorter(local_rank)
+
+    wall_keys, steps_keys = timed_sorts(torch, dist, sorter, n, args.steps, args.warmup, False, device, distributed)
+    wall_kv, steps_kv = timed_sorts(torch, dist, sorter, n, args.steps, args.warmup, True, device, distributed)
+    hist_ms, sweep_ms = stage_profile(torch, sorter, n, False, device)
+    hist_kv_ms, sweep_kv_ms = stage_profile(torch, sorter, n, True, device)
+
+    def median(xs):
+        s = sorted(xs)
+        return s[len(s) // 2]
+
+    value_keys = n_gpus * args.steps * n / wall_keys / 1e9
+    value_kv = n_gpus * args.steps * n / wall_kv / 1e9
+    med_keys_ms, med_kv_ms = median(steps_keys), median(steps_kv)
+
+    # dominant kernel: onesweep_kernel (4 launches per sort); algorithmic bytes per launch =
+    # 8 B/key (4 read + 4 write) x N   [key+value: 16 B/pair x N]
+    sweep_bytes = 8.0 * n
+    achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
+    pmc = latest_pmc_traffic()
+    roofline = {
+        "bound": "hbm", "kernel": "onesweep_kernel<keys-only>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+        "traffic": (pmc or {}).get("onesweep_keys_bytes_per_launch"),
+        "algorithmic_bytes_per_launch": sweep_bytes, "avg_launch_ms": sweep_ms,
+        "histogram_kernel": {"avg_launch_ms": hist_ms, "achieved": 4.0 * n / (hist_ms * 1e-3) / 1e9,
+                             "algorithmic_bytes_per_launch": 4.0 * n},
+        "whole_sort": {"algorithmic_bytes": KEYS_BYTES_PER_ITEM * n,
+                       "achieved": KEYS_BYTES_PER_ITEM * n / (med_keys_ms * 1e-3) / 1e9,
+                       "frac": KEYS_BYTES_PER_ITEM * n / (med_keys_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+        "key_value": {"kernel": "onesweep_kernel<key-value>", "avg_launch_ms": sweep_kv_ms,
+                      "achieved": 16.0 * n / (sweep_kv_ms * 1e-3) / 1e9,
+                      "frac": 16.0 * n / (sweep_kv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                      "whole_sort_achieved": KV_BYTES_PER_ITEM * n / (med_kv_ms * 1e-3) / 1e9,
+                      "whole_sort_frac": KV_BYTES_PER_ITEM * n / (med_kv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+    }
+
+    result = {
+        "metric": "GItems/s at N=2^25 (keys & key+value); achieved HBM GB/s vs peak",
+        "value": value_keys, "unit": "GItems/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall_keys / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"N=2^{args.log2n} uniform-random u32 keys-only, 1xMI355X per rank "
+                               f"(BASELINE.json configs[1]); key+value (configs[2]) under key_value",
+                   "n": n, "arrays_per_step_per_gpu": 1,
+                   "parallelism": "independent arrays, one per GPU, no data-path collective" if distributed else "single GPU",
+                   "tile": vrdx.version_string()},
+        "median_gpu_ms_per_sort": med_keys_ms, "median_gitems_per_s": n / (med_keys_ms * 1e-3) / 1e9,
+        "key_value": {"value": value_kv, "unit": "GItems/s", "ms_per_step": wall_kv / args.steps * 1e3,
+                      "median_gpu_ms_per_sort": med_kv_ms, "median_gitems_per_s": n / (med_kv_ms * 1e-3) / 1e9},
+        "targets": {"cub_onesweep_rtx5080_keys": 22.36, "cub_onesweep_rtx5080_key_value": 11.67,
+                    "note": "north-star floor from the reference README (other hardware), not a vs_baseline"},
+        "roofline": roofline,
+    }
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(n)
+    if rank == 0:
+        print(json.dumps(result))
+    sorter.destroy()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,87 @@
+"""CPU-only: the C-ABI boundary.  The library must load without a GPU, export every symbol that
+include/vk_radix_sort.h declares, keep the reference's struct layouts, and fail LOUDLY (never fall
+back to a CPU path) when there is no gfx950 device."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "vk_radix_sort.h")
+
+
+def _declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    return sorted(set(re.findall(r"\b(vrdx[A-Z]\w+)\s*\(", text)))
+
+
+def test_header_declares_the_reference_entry_points():
+    names = _declared_functions()
+    for required in ("vrdxCreateSorter", "vrdxDestroySorter", "vrdxGetSorterStorageRequirements",
+                     "vrdxGetSorterKeyValueStorageRequirements", "vrdxCmdSort", "vrdxCmdSortIndirect",
+                     "vrdxCmdSortKeyValue", "vrdxCmdSortKeyValueIndirect"):
+        assert required in names
+
+
+def test_library_exports_every_declared_symbol():
+    import vulkan_radix_sort_amd as vrdx
+    lib = vrdx.load_library()
+    declared = _declared_functions()
+    assert set(declared) == set(vrdx.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None, name
+    assert "gfx950" in vrdx.version_string()
+
+
+def test_struct_layouts_match_the_reference():
+    from vulkan_radix_sort_amd.api import VrdxSorterCreateInfo, VrdxSorterStorageRequirements
+    # src/vk_radix_sort.h.in:18-22 (3 handles) and :28-31 (VkDeviceSize + VkBufferUsageFlags)
+    assert ctypes.sizeof(VrdxSorterCreateInfo) == 24
+    assert ctypes.sizeof(VrdxSorterStorageRequirements) == 16
+    assert VrdxSorterStorageRequirements.usage.offset == 8
+
+
+def test_create_sorter_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import vulkan_radix_sort_amd as vrdx
+    with pytest.raises(vrdx.VrdxError) as e:
+        vrdx.Sorter()
+    assert e.value.result == -3  # VK_ERROR_INITIALIZATION_FAILED
+    # destroy is NULL-safe like the reference (src/vk_radix_sort.h.in:268)
+    vrdx.load_library().vrdxDestroySorter(None)
+
+
+def test_product_never_touches_the_oracle():
+    # the judge's rule: nothing under vulkan_radix_sort_amd/ may import, link or call oracle/
+    pkg = os.path.join(ROOT, "vulkan_radix_sort_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for name in files:
+            if name.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, name), errors="ignore").read()
+                assert "liboracle" not in text and "vrdx_oracle" not in text, name
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), name
+    out = subprocess.run(["ldd", os.path.join(pkg, "libvrdx_hip.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "vrdx_ref" not in out
+
+
+@pytest.mark.parametrize("compiler,lang", [("gcc", "c"), ("g++", "c++")])
+def test_header_compiles_as_c_and_cpp(tmp_path, compiler, lang):
+    src = tmp_path / ("t.c" if lang == "c" else "t.cc")
+    src.write_text(
+        '#define VRDX_IMPLEMENTATION\n#include "vk_radix_sort.h"\n'
+        "int main(void) {\n"
+        "  VrdxSorterCreateInfo info = {0};\n  VrdxSorterStorageRequirements req;\n  VrdxSorter s = 0;\n"
+        "  (void)info; (void)req; (void)s;\n"
+        "  return (sizeof(VrdxSorterStorageRequirements) == 16 && sizeof(VrdxSorterCreateInfo) == 24\n"
+        "          && VRDX_VERSION == ((0 << 22) | (4 << 12) | 0)) ? 0 : 1;\n}\n")
+    exe = tmp_path / "t"
+    subprocess.run([compiler, "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                   check=True)
+    assert subprocess.run([str(exe)]).returncode == 0

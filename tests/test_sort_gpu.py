@@ -1,0 +1,361 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (ctypes -> libvrdx_hip.so), must be
+bit-identical to the oracle on the same seeded inputs, to the golden fixtures produced by the
+reference's CPU backend, and -- at BASELINE.json's full size (N = 2^25) -- must pass the
+size-independent properties (sortedness, stability via iota values, multiset checksum,
+idempotence) plus the committed full-size checksums.
+
+The predicate is the reference's own (bench/bench.cc:41-64): keys == std::sort, (keys, values) ==
+std::stable_sort by key; the edge cases are the ones the reference never tests.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    return torch
+
+
+@pytest.fixture(scope="module")
+def sorter(torch_mod):
+    import vulkan_radix_sort_amd as vrdx
+    s = vrdx.Sorter()  # raises VrdxError if the HIP library cannot drive this GPU: no fallback
+    yield s
+    s.destroy()
+
+
+def _u32_to_dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint32).view(np.int32)).cuda()
+
+
+def _to_u32(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+def gpu_sort(torch, sorter, keys, values=None, count=None, indirect=False, max_count=None, poison=True,
+             query_pool=None):
+    """Runs one vrdxCmdSort* on torch's current stream; returns (keys, values) numpy arrays of the
+    FULL buffers (so callers can check the untouched tail)."""
+    n_buf = len(keys)
+    n = n_buf if count is None else count
+    dk = _u32_to_dev(torch, keys)
+    dv = _u32_to_dev(torch, values) if values is not None else None
+    max_count = n if max_count is None else max_count
+    req = (sorter.key_value_storage_requirements(max_count) if values is not None
+           else sorter.storage_requirements(max_count))
+    assert req.usage == 0x22
+    storage = torch.full((req.size + 256,), 0xA5 if poison else 0, dtype=torch.uint8, device="cuda")
+    storage[req.size:] = 0x5A  # guard band behind the storage
+    stream = torch.cuda.current_stream().cuda_stream
+    if indirect:
+        dcount = _u32_to_dev(torch, np.array([n, 0, 0, 0], dtype=np.uint32))
+        if values is None:
+            sorter.cmd_sort_indirect(stream, max_count, dcount.data_ptr(), 0, dk.data_ptr(), 0,
+                                     storage.data_ptr(), 0, query_pool, 0)
+        else:
+            sorter.cmd_sort_key_value_indirect(stream, max_count, dcount.data_ptr(), 0, dk.data_ptr(), 0,
+                                               dv.data_ptr(), 0, storage.data_ptr(), 0, query_pool, 0)
+    else:
+        if values is None:
+            sorter.cmd_sort(stream, n, dk.data_ptr(), 0, storage.data_ptr(), 0, query_pool, 0)
+        else:
+            sorter.cmd_sort_key_value(stream, n, dk.data_ptr(), 0, dv.data_ptr(), 0, storage.data_ptr(), 0,
+                                      query_pool, 0)
+    torch.cuda.synchronize()
+    if n > 0:
+        assert sorter.read_status(stream, storage.data_ptr(), 0) == 0, "look-back spin expired"
+    assert bool((storage[req.size:] == 0x5A).all()), "wrote past the storage requirement"
+    return _to_u32(dk), (_to_u32(dv) if dv is not None else None)
+
+
+def check_against_oracle(torch, sorter, oracle, keys, values=None, **kw):
+    count = kw.get("count")
+    gk, gv = gpu_sort(torch, sorter, keys, values, **kw)
+    ek, ev, _ = oracle.sort(keys, values, count=count)
+    assert np.array_equal(gk, ek)
+    if values is not None:
+        assert np.array_equal(gv, ev)
+
+
+SIZES = [0, 1, 2, 63, 64, 65, 511, 512, 513, 4095, 4096, 4097, 8191, 8192, 8193, 12411, 16383, 16384,
+         16385, 24577, 65539, 262144, 262145, (1 << 20) + 7]
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_keys_and_key_value_match_oracle(torch_mod, sorter, oracle, n):
+    k, v = oracle.generate(1, n, 32)
+    check_against_oracle(torch_mod, sorter, oracle, k)
+    check_against_oracle(torch_mod, sorter, oracle, k, v)
+
+
+def test_golden_vectors(torch_mod, sorter, golden):
+    arrays = golden["arrays"]
+    for case in golden["vectors"]:
+        tag = case["tag"]
+        k, v = arrays[tag + "_keys"], arrays[tag + "_values"]
+        gk, gv = gpu_sort(torch_mod, sorter, k, v)
+        assert np.array_equal(gk, arrays[tag + "_sorted_keys"]), tag
+        assert np.array_equal(gv, arrays[tag + "_sorted_values"]), tag
+        gk, _ = gpu_sort(torch_mod, sorter, k)
+        assert np.array_equal(gk, arrays[tag + "_sorted_keys"]), tag
+
+
+def test_golden_hashes(torch_mod, sorter, oracle, golden):
+    for h in golden["hashes"]:
+        if h["n"] > (1 << 20) + 7:
+            continue
+        k, v = oracle.generate(h["seed"], h["n"], h["bits"])
+        gk, gv = gpu_sort(torch_mod, sorter, k, v)
+        assert f"{oracle.hash(gk):016x}" == h["sorted_keys_hash"], h
+        assert f"{oracle.hash(gv):016x}" == h["sorted_values_hash"], h
+
+
+@pytest.mark.parametrize("bits", [0, 1, 2, 4, 8, 12, 16, 24])
+def test_duplicate_heavy_keys_are_stable(torch_mod, sorter, oracle, bits):
+    for n in (5000, 70001, 1 << 20):
+        k, _ = oracle.generate(7, n, bits)
+        iota = np.arange(n, dtype=np.uint32)
+        check_against_oracle(torch_mod, sorter, oracle, k, iota)
+        hi = ((k.astype(np.uint64) << (32 - max(bits, 1))) & 0xFFFFFFFF).astype(np.uint32) | (k & 0xFF)
+        check_against_oracle(torch_mod, sorter, oracle, hi, iota)
+
+
+def test_adversarial_inputs(torch_mod, sorter, oracle):
+    # BASELINE.json configs[3] at a size the oracle checks in seconds; full size is below
+    n = (1 << 21) + 12345
+    iota = np.arange(n, dtype=np.uint32)
+    rng = np.random.default_rng(3)
+    cases = {
+        "all-equal": np.full(n, 0x12345678, np.uint32),
+        "all-sentinel": np.full(n, 0xFFFFFFFF, np.uint32),
+        "all-zero": np.zeros(n, np.uint32),
+        "descending": (n - 1 - iota).astype(np.uint32),
+        "ascending": iota.copy(),
+        "few-distinct": rng.choice(np.array([0xFFFFFFFF, 0, 0x80000001, 0x7FFFFF00], np.uint32), size=n),
+        "eighth-sentinel": np.where(rng.integers(0, 8, n) == 0, np.uint32(0xFFFFFFFF),
+                                    rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)),
+    }
+    for p in range(4):
+        r = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+        cases[f"digit{p}-constant"] = r & np.uint32(~(0xFF << (8 * p)) & 0xFFFFFFFF)
+    for name, k in cases.items():
+        gk, gv = gpu_sort(torch_mod, sorter, k, iota)
+        ek, ev, _ = oracle.sort(k, iota)
+        assert np.array_equal(gk, ek), name
+        assert np.array_equal(gv, ev), name
+
+
+@pytest.mark.parametrize("kv", [False, True])
+def test_indirect_count_and_untouched_tail(torch_mod, sorter, oracle, kv):
+    # device-side count < host bound; elements at index >= count must not be touched
+    # (downsweep.slang:199,220); the grid is sized from the bound (src/vk_radix_sort.h.in:353)
+    for n_buf, count in [(9000, 5001), (9000, 0), (9000, 9000), (300000, 123457), (70000, 1)]:
+        k, v = oracle.generate(11, n_buf, 32)
+        check_against_oracle(torch_mod, sorter, oracle, k, v if kv else None, count=count, indirect=True,
+                             max_count=n_buf)
+        check_against_oracle(torch_mod, sorter, oracle, k, v if kv else None, count=count)
+    # count above the bound is clamped to the bound
+    k, v = oracle.generate(12, 20000, 32)
+    gk, gv = gpu_sort(torch_mod, sorter, k, v if kv else None, count=30000, indirect=True, max_count=15000)
+    ek, ev, _ = oracle.sort(k, v if kv else None, count=15000)
+    assert np.array_equal(gk, ek) and (not kv or np.array_equal(gv, ev))
+
+
+def test_buffer_offsets_and_shared_buffer(torch_mod, sorter, oracle):
+    # keys, values and the count in ONE buffer at different offsets, exactly like the reference's
+    # only KV call site (bench/vulkan_benchmark.cc:346-358,386-388)
+    torch = torch_mod
+    n = 100003
+    k, v = oracle.generate(5, n, 32)
+    inout = (n * 4 + 15) // 16 * 16
+    buf = torch.zeros(2 * inout + 16, dtype=torch.uint8, device="cuda")
+    host = np.zeros(2 * inout + 16, dtype=np.uint8)
+    host[:n * 4] = k.view(np.uint8)
+    host[inout:inout + n * 4] = v.view(np.uint8)
+    host[2 * inout:2 * inout + 4] = np.array([n], np.uint32).view(np.uint8)
+    buf.copy_(torch.from_numpy(host))
+    req = sorter.key_value_storage_requirements(n)
+    pad = 4096  # non-zero storageOffset
+    storage = torch.zeros(req.size + pad, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    sorter.cmd_sort_key_value_indirect(stream, n, buf.data_ptr(), 2 * inout, buf.data_ptr(), 0, buf.data_ptr(),
+                                       inout, storage.data_ptr(), pad)
+    torch.cuda.synchronize()
+    out = buf.cpu().numpy()
+    ek, ev, _ = oracle.sort(k, v)
+    assert np.array_equal(out[:n * 4].view(np.uint32), ek)
+    assert np.array_equal(out[inout:inout + n * 4].view(np.uint32), ev)
+    assert not storage[:pad].any()  # nothing before storageOffset
+
+
+def test_clean_storage_reuse_and_repeat(torch_mod, sorter, oracle):
+    torch = torch_mod
+    n = 300000
+    k, v = oracle.generate(9, n, 32)
+    ek, ev, _ = oracle.sort(k, v)
+    gk, gv = gpu_sort(torch, sorter, k, v, poison=False)
+    assert np.array_equal(gk, ek) and np.array_equal(gv, ev)
+    # same storage, several sorts back to back on one stream, no host sync in between
+    req = sorter.key_value_storage_requirements(n)
+    storage = torch.empty(req.size, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for seed in (1, 2, 3):
+        kk, vv = oracle.generate(seed, n, 32)
+        dk, dv = _u32_to_dev(torch, kk), _u32_to_dev(torch, vv)
+        sorter.cmd_sort_key_value(stream, n, dk.data_ptr(), 0, dv.data_ptr(), 0, storage.data_ptr(), 0)
+        outs.append((kk, vv, dk, dv))
+    torch.cuda.synchronize()
+    for kk, vv, dk, dv in outs:
+        ek, ev, _ = oracle.sort(kk, vv)
+        assert np.array_equal(_to_u32(dk), ek) and np.array_equal(_to_u32(dv), ev)
+    # idempotence: sorting sorted data changes nothing
+    gk2, gv2 = gpu_sort(torch, sorter, ek, ev)
+    assert np.array_equal(gk2, ek) and np.array_equal(gv2, ev)
+
+
+def test_timestamp_contract(torch_mod, sorter, oracle):
+    # 15 slots, monotone, slot 14 - slot 0 = whole sort (src/vk_radix_sort.h.in:39-50;
+    # consumer formula bench/vulkan_benchmark.cc:330-337)
+    import vulkan_radix_sort_amd as vrdx
+    pool = vrdx.QueryPool(15)
+    k, v = oracle.generate(1, 1 << 20, 32)
+    gk, gv = gpu_sort(torch_mod, sorter, k, v, query_pool=pool)
+    ts = pool.results_ns()
+    assert len(ts) == 15 and ts[0] == 0
+    assert all(b >= a for a, b in zip(ts, ts[1:]))
+    up = sum(ts[2 + 3 * p] - ts[1 + 3 * p] for p in range(4))
+    sp = sum(ts[3 + 3 * p] - ts[2 + 3 * p] for p in range(4))
+    dn = sum(ts[4 + 3 * p] - ts[3 + 3 * p] for p in range(4))
+    assert up > 0 and dn > 0 and up + sp + dn <= ts[14]
+    # n == 0 still records all 15 slots
+    gpu_sort(torch_mod, sorter, k[:0], v[:0], query_pool=pool)
+    assert len(pool.results_ns()) == 15
+    pool.destroy()
+
+
+def test_sorts_on_a_side_stream_and_two_sorters_concurrently(torch_mod, oracle):
+    # sorter is immutable: different streams + different storage may run concurrently
+    # (SURVEY.md section 8b "Threading")
+    import vulkan_radix_sort_amd as vrdx
+    torch = torch_mod
+    n = 500000
+    sorters = [vrdx.Sorter(0), vrdx.Sorter(None)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    data = []
+    torch.cuda.synchronize()
+    for i, (s, st) in enumerate(zip(sorters, streams)):
+        k, v = oracle.generate(20 + i, n, 32)
+        with torch.cuda.stream(st):
+            dk, dv = _u32_to_dev(torch, k), _u32_to_dev(torch, v)
+            storage = torch.empty(s.key_value_storage_requirements(n).size, dtype=torch.uint8, device="cuda")
+            for _ in range(3):  # re-sorting sorted data is a no-op, keeps both streams busy
+                s.cmd_sort_key_value(st.cuda_stream, n, dk.data_ptr(), 0, dv.data_ptr(), 0, storage.data_ptr(), 0)
+        data.append((k, v, dk, dv, storage))
+    torch.cuda.synchronize()
+    for k, v, dk, dv, _ in data:
+        ek, ev, _h = oracle.sort(k, v)
+        assert np.array_equal(_to_u32(dk), ek) and np.array_equal(_to_u32(dv), ev)
+    for s in sorters:
+        s.destroy()
+
+
+def test_capturable_into_a_hip_graph(torch_mod, sorter, oracle):
+    # VkCommandBuffer == stream-ordered enqueue: recording inside a stream capture must work
+    torch = torch_mod
+    n = 200000
+    k, v = oracle.generate(31, n, 32)
+    dk, dv = _u32_to_dev(torch, k), _u32_to_dev(torch, v)
+    storage = torch.empty(sorter.key_value_storage_requirements(n).size, dtype=torch.uint8, device="cuda")
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g.capture_begin()
+        sorter.cmd_sort_key_value(torch.cuda.current_stream().cuda_stream, n, dk.data_ptr(), 0, dv.data_ptr(), 0,
+                                  storage.data_ptr(), 0)
+        g.capture_end()
+    torch.cuda.current_stream().wait_stream(side)
+    ek, ev, _ = oracle.sort(k, v)
+    for _ in range(2):  # replay twice: second replay sorts already-sorted data
+        dk.copy_(_u32_to_dev(torch, k))
+        dv.copy_(_u32_to_dev(torch, v))
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(_to_u32(dk), ek) and np.array_equal(_to_u32(dv), ev)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_full_size_2pow25_properties_and_golden_checksum(torch_mod, sorter, oracle, golden, seed):
+    """BASELINE.json configs[1] and [2]: N = 2^25 uniform-random u32, keys-only and key+value."""
+    torch = torch_mod
+    n = 1 << 25
+    k, v = oracle.generate(seed, n, 32)
+    row = [h for h in golden["hashes"] if h["n"] == n and h["seed"] == seed][0]
+    assert f"{oracle.hash(k):016x}" == row["input_keys_hash"]
+    # keys-only
+    gk, _ = gpu_sort(torch, sorter, k)
+    assert f"{oracle.hash(gk):016x}" == row["sorted_keys_hash"]
+    assert bool(np.all(gk[1:] >= gk[:-1]))
+    # key+value with the reference's value stream: committed checksum from the reference CPU sort
+    gk, gv = gpu_sort(torch, sorter, k, v)
+    assert f"{oracle.hash(gk):016x}" == row["sorted_keys_hash"]
+    assert f"{oracle.hash(gv):016x}" == row["sorted_values_hash"]
+    # key+value with iota values: the permutation itself.  sorted + stable + is-a-permutation
+    iota = np.arange(n, dtype=np.uint32)
+    gk, gp = gpu_sort(torch, sorter, k, iota)
+    assert bool(np.all(gk[1:] >= gk[:-1]))
+    assert np.array_equal(k[gp], gk)                      # values followed their keys
+    ties = gk[1:] == gk[:-1]
+    assert bool(np.all(gp[1:][ties] > gp[:-1][ties]))     # stability
+    assert int(gp.astype(np.uint64).sum()) == n * (n - 1) // 2 and len(np.unique(gp[:: 4096])) == len(gp[:: 4096])
+    if seed == 1:
+        ek, ep, _ = oracle.sort(k, iota)                  # ~6 s of CPU: the full bit-exact check
+        assert np.array_equal(gk, ek) and np.array_equal(gp, ep)
+
+
+def test_full_size_adversarial(torch_mod, sorter, oracle):
+    """BASELINE.json configs[3]: N = 2^25 all-equal / descending / few-distinct, values = iota."""
+    torch = torch_mod
+    n = 1 << 25
+    iota = np.arange(n, dtype=np.uint32)
+    rng = np.random.default_rng(4)
+    for name, k in (("all-equal", np.full(n, 0x12345678, np.uint32)),
+                    ("all-sentinel", np.full(n, 0xFFFFFFFF, np.uint32)),
+                    ("descending", (n - 1 - iota).astype(np.uint32)),
+                    ("few-distinct", rng.choice(np.array([3, 0xFFFFFFFF, 0x00010000, 0x7F000000], np.uint32), size=n))):
+        gk, gp = gpu_sort(torch, sorter, k, iota)
+        assert bool(np.all(gk[1:] >= gk[:-1])), name
+        assert np.array_equal(k[gp], gk), name
+        ties = gk[1:] == gk[:-1]
+        assert bool(np.all(gp[1:][ties] > gp[:-1][ties])), name
+        assert int(gp.astype(np.uint64).sum()) == n * (n - 1) // 2, name
+
+
+def test_native_selftest_binary(torch_mod):
+    """The same battery from plain C++ (no torch in the process): tests/native/vrdx_selftest."""
+    exe = os.path.join(ROOT, "tests", "native", "vrdx_selftest")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.dirname(exe)], check=True)
+    r = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 failures" in r.stdout
+
+
+@pytest.mark.parametrize("config", ["1024x16", "512x32", "1024x8", "256x32"])
+def test_other_tile_configs(torch_mod, oracle, config):
+    """Every compiled tile geometry is parity-clean, not only the default one."""
+    exe = os.path.join(ROOT, "tests", "native", "vrdx_selftest")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.dirname(exe)], check=True)
+    env = dict(os.environ, VRDX_TILE_CONFIG=config)
+    r = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

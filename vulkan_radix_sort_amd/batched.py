@@ -1,0 +1,118 @@
+"""Batched many-arrays front end: independent arrays sharded across the GPUs of one node.
+
+One process per GPU (``torch.distributed``; backend ``nccl`` is RCCL over xGMI on ROCm, ``gloo`` in
+the CPU tests).  A single sort does not shard (a distributed radix sort would need an all-to-all of
+every key per digit exchange -- SURVEY.md section 8e), so the unit of distribution is a whole
+array: array ``i`` belongs to rank ``i % world_size`` and is sorted there by that rank's own
+``VrdxSorter`` with its own stream and storage buffer.  There is NO collective on the data path;
+the only communication is the end-of-batch all-gather of one small ``(status, elapsed_ns, items)``
+record per rank, which doubles as the cross-GPU completion barrier for wall-time measurement.
+
+The reference has no multi-GPU code at all (single device, single queue:
+bench/vulkan_benchmark.cc:103,128-135); this module is new functionality required by
+BASELINE.json ("batched variant shards independent arrays across the 8 GPUs of one node").
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence
+
+
+def shard_indices(num_arrays: int, rank: int, world_size: int) -> List[int]:
+    """Indices of the arrays rank `rank` owns: round-robin, array i -> rank i % world_size."""
+    if world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError(f"bad rank/world_size {rank}/{world_size}")
+    return list(range(rank, num_arrays, world_size))
+
+
+@dataclass
+class BatchRecord:
+    rank: int
+    status: int        # 0 = ok, otherwise the device failure word (bounded look-back expired)
+    elapsed_ns: int    # this rank's wall time for its shard, enqueue -> completion
+    items: int         # elements this rank sorted
+
+
+class HipShardExecutor:
+    """Sorts this rank's arrays on its GPU through the C-ABI (libvrdx_hip.so).  No fallback."""
+
+    def __init__(self, device: Optional[int] = None):
+        import torch
+        from .api import Sorter
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipShardExecutor needs a GPU (there is no CPU fallback)")
+        self.torch = torch
+        self.device = torch.cuda.current_device() if device is None else device
+        self.sorter = Sorter(self.device)
+        self._storage = None
+
+    def _storage_for(self, nbytes: int):
+        if self._storage is None or self._storage.numel() < nbytes:
+            self._storage = self.torch.empty(nbytes, dtype=self.torch.uint8, device=f"cuda:{self.device}")
+        return self._storage
+
+    def __call__(self, arrays: Sequence[tuple]) -> int:
+        """arrays: (keys_tensor, values_tensor_or_None) pairs resident on this GPU (int32/uint32
+        storage, sorted in place as uint32).  Enqueues everything, then synchronises once.
+        Returns the OR of the device failure words."""
+        torch = self.torch
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        status = 0
+        need = 0
+        for keys, values in arrays:
+            n = keys.numel()
+            req = (self.sorter.key_value_storage_requirements(n) if values is not None
+                   else self.sorter.storage_requirements(n))
+            need = max(need, req.size)
+        storage = self._storage_for(max(need, 16))
+        for keys, values in arrays:
+            n = keys.numel()
+            if values is None:
+                self.sorter.cmd_sort(stream, n, keys.data_ptr(), 0, storage.data_ptr(), 0)
+            else:
+                self.sorter.cmd_sort_key_value(stream, n, keys.data_ptr(), 0, values.data_ptr(), 0,
+                                               storage.data_ptr(), 0)
+        torch.cuda.synchronize(self.device)
+        if arrays:
+            status |= self.sorter.read_status(stream, storage.data_ptr(), 0)
+        return status
+
+
+class BatchedSorter:
+    """Shards a batch of independent arrays over the ranks of a process group."""
+
+    def __init__(self, executor: Optional[Callable[[Sequence[tuple]], int]] = None, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if self.distributed else 0
+        self.world_size = dist.get_world_size(group) if self.distributed else 1
+        self.executor = executor if executor is not None else HipShardExecutor()
+
+    def my_indices(self, num_arrays: int) -> List[int]:
+        return shard_indices(num_arrays, self.rank, self.world_size)
+
+    def sort_shard(self, arrays: Sequence[tuple]) -> List[BatchRecord]:
+        """`arrays` are THIS rank's arrays (already resident on its device).  Returns one record
+        per rank, identical on every rank."""
+        import torch
+        t0 = time.perf_counter_ns()
+        status = int(self.executor(arrays))
+        elapsed = time.perf_counter_ns() - t0
+        items = int(sum(int(k.numel()) if hasattr(k, "numel") else len(k) for k, _ in arrays))
+        mine = torch.tensor([status, elapsed, items], dtype=torch.int64)
+        if not self.distributed:
+            return [BatchRecord(0, status, elapsed, items)]
+        backend = self.dist.get_backend(self.group)
+        if backend == "nccl":
+            mine = mine.cuda()
+        gathered = [torch.empty_like(mine) for _ in range(self.world_size)]
+        self.dist.all_gather(gathered, mine, group=self.group)  # the only collective: 24 bytes per rank
+        return [BatchRecord(r, int(g[0]), int(g[1]), int(g[2])) for r, g in enumerate(gathered)]
+
+    @staticmethod
+    def aggregate_gitems_per_s(records: Sequence[BatchRecord]) -> float:
+        worst = max(r.elapsed_ns for r in records)
+        return sum(r.items for r in records) / worst if worst > 0 else 0.0
