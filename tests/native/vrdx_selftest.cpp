@@ -188,6 +188,50 @@ std::vector<uint32_t> Mt(uint32_t n, int seed, uint32_t bits, std::vector<uint32
   return k;
 }
 
+
+// VkCommandBuffer == stream-ordered enqueue: vrdxCmdSort* must be capturable into a hipGraph
+// (no query pool inside a capture) and the graph must be replayable.
+bool GraphCase(Harness& h, bool kv, uint32_t n) {
+  std::vector<uint32_t> v;
+  auto k = Mt(n, 31, 32, &v);
+  const uint32_t inout = Align16(n * 4u);
+  VrdxSorterStorageRequirements req;
+  if (kv)
+    vrdxGetSorterKeyValueStorageRequirements(h.sorter, n, &req);
+  else
+    vrdxGetSorterStorageRequirements(h.sorter, n, &req);
+  h.reserve((size_t)2 * inout + 16, (size_t)req.size + 256);
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  HIP_OK(hipStreamBeginCapture(h.stream, hipStreamCaptureModeGlobal));
+  if (kv)
+    vrdxCmdSortKeyValue((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dKeys, inout,
+                        (VkBuffer)h.dStorage, 0, VK_NULL_HANDLE, 0);
+  else
+    vrdxCmdSort((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dStorage, 0, VK_NULL_HANDLE, 0);
+  HIP_OK(hipStreamEndCapture(h.stream, &graph));
+  size_t nodes = 0;
+  HIP_OK(hipGraphGetNodes(graph, nullptr, &nodes));
+  HIP_OK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  std::vector<uint32_t> ek = k, ev = v;
+  vrdx_oracle_sort(ek.data(), kv ? ev.data() : nullptr, n, nullptr);
+  bool ok = nodes >= 6;
+  for (int replay = 0; replay < 3 && ok; ++replay) {
+    HIP_OK(hipMemcpy(h.dKeys, k.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(h.dKeys + inout, v.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipGraphLaunch(exec, h.stream));
+    HIP_OK(hipStreamSynchronize(h.stream));
+    std::vector<uint32_t> gk(n), gv(n);
+    HIP_OK(hipMemcpy(gk.data(), h.dKeys, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(gv.data(), h.dKeys + inout, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (gk != ek || (kv && gv != ev)) ok = false;
+  }
+  HIP_OK(hipGraphExecDestroy(exec));
+  HIP_OK(hipGraphDestroy(graph));
+  if (!ok) std::printf("FAIL hipGraph capture/replay %s n=%u nodes=%zu\n", kv ? "kv" : "keys", n, nodes);
+  return ok;
+}
+
 int Parity(Harness& h, bool quick) {
   int failures = 0, cases = 0;
   auto run = [&](Mode m, const std::vector<uint32_t>& k, const std::vector<uint32_t>& v, uint32_t maxCount,
@@ -278,6 +322,11 @@ int Parity(Harness& h, bool quick) {
     run(Mode::KeyValue, k, v, 300000, "storage reuse");
     run(Mode::Keys, k, v, 300000, "storage reuse");
   }
+  for (int kv = 0; kv < 2; ++kv)
+    for (uint32_t n : {5000u, 200000u, 3000000u}) {
+      ++cases;
+      if (!GraphCase(h, kv != 0, n)) ++failures;
+    }
   std::printf("parity: %d cases, %d failures\n", cases, failures);
   return failures;
 }

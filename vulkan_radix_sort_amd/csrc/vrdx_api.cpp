@@ -24,6 +24,7 @@ struct VrdxSorter_T {
   int computeUnits = 0;
   int configIndex = 0;
   uint32_t tileKeys = 0;
+  bool atomicRank = false;  // LDS returning atomics proven lane-ordered on this device
   // reference: VrdxSorter_T::minStorageBufferOffsetAlignment (src/vk_radix_sort.h.in:134)
   uint32_t minStorageBufferOffsetAlignment = VRDX_STORAGE_ALIGN;
 };
@@ -143,7 +144,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     args.ticketNext = tickets + ((pass + 1) & 1u);
     args.failure = failure;
     args.shift = 8 * pass;
-    vrdx::LaunchOnesweep(stream, sorter->configIndex, tiles, keyValue, args);
+    vrdx::LaunchOnesweep(stream, sorter->configIndex, tiles, keyValue, sorter->atomicRank, args);
 
     Stamp(pool, query + 2 + 3 * pass + 2, stream);  // "downsweep"
   }
@@ -183,6 +184,20 @@ VkResult vrdxCreateSorter(const VrdxSorterCreateInfo* pCreateInfo, VrdxSorter* p
   (void)hipGetDevice(&previous);
   hipError_t e = hipSetDevice(ordinal);
   if (e == hipSuccess) e = vrdx::PrepareKernels(sorter->configIndex);
+  if (e == hipSuccess) {
+    // Ranking mode: the single-atomic form needs a hardware property the ISA manual does not
+    // promise, so it is verified here, once, on this very device; VRDX_RANK=ballot|atomic|auto.
+    const char* mode = std::getenv("VRDX_RANK");
+    if (mode != nullptr && std::strcmp(mode, "ballot") == 0) {
+      sorter->atomicRank = false;
+    } else {
+      bool ordered = false;
+      e = vrdx::LdsOrderCheck(&ordered);
+      sorter->atomicRank = ordered;
+      if (e == hipSuccess && !ordered && mode != nullptr && std::strcmp(mode, "atomic") == 0)
+        std::fprintf(stderr, "vrdx-hip: VRDX_RANK=atomic refused, LDS atomics are not lane-ordered here\n");
+    }
+  }
   (void)hipSetDevice(previous);
   if (e != hipSuccess) {
     delete sorter;  // reference cleanup(): nothing half-built survives (:153-158)

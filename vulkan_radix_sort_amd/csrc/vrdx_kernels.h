@@ -44,8 +44,13 @@ hipError_t PrepareKernels(int configIndex);
 void LaunchHistogram(hipStream_t stream, uint32_t grid, const uint32_t* keys, uint32_t maxCount,
                      const uint32_t* countPtr, uint32_t* globalHistogram);
 
-void LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool keyValue,
+// atomicRank selects the one-LDS-atomic-per-key ranking; only legal when LdsOrderCheck() said so.
+void LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool keyValue, bool atomicRank,
                     const OnesweepArgs& args);
+
+// Runs the device self-check of the LDS same-address atomic ordering on the current device
+// (synchronous, ~1 ms).  *laneOrdered = true when returning atomics are served in lane order.
+hipError_t LdsOrderCheck(bool* laneOrdered);
 
 }  // namespace vrdx
 

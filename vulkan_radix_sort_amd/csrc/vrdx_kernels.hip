@@ -25,6 +25,14 @@
 
 namespace vrdx {
 
+// Timing-only ablation switches for tools/ablate.sh (results are WRONG when any bit is set; the
+// product build always has VRDX_ABLATE == 0):  1 no look-back   2 no match ranking
+// 4 linear instead of scattered stores   8 tile = blockIdx (no ticket)   16 no wave counters
+#ifndef VRDX_ABLATE
+#define VRDX_ABLATE 0
+#endif
+constexpr uint32_t kAblate = VRDX_ABLATE;
+
 // ---------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t*
 // prefix.  kWindow status words are requested per trip so that their latencies overlap.
 __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t tile, uint32_t digit,
                                              uint32_t* failure) {
-  constexpr int kWindow = 4;
+  constexpr int kWindow = 8;
   constexpr uint32_t kSpinLimit = 1u << 20;
   uint32_t exclusive = 0;
   int32_t j = (int32_t)tile - 1;
@@ -196,7 +204,60 @@ __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t ti
   return exclusive;
 }
 
-template <int THREADS, int KPT, bool KV>
+// Stable rank of one key slot inside its wave, two interchangeable ways (same results):
+//
+//  * RankBallot  -- match-any with 8 ballots; leader lane bumps the wave-private digit counter.
+//    Uses only architecturally defined behaviour.  ~90 VALU instructions per slot.
+//  * RankAtomic  -- one returning LDS atomic per key: old = ds_add_rtn_u32(counter[digit], 1).
+//    Several lanes of ONE instruction hitting one address are served in ascending lane order on
+//    gfx950, which is exactly the stable order; the ISA manual does not promise that order, so
+//    vrdxCreateSorter verifies it on the actual device (LdsOrderCheck below) and selects the
+//    ballot form if the check ever fails.  A wave whose 64 digits are all equal (sorted or
+//    constant inputs in the high passes) is handled by one lane adding 64, so the adversarial
+//    inputs do not serialise 64-way on one LDS address.
+//
+// Counters are wave-private and LDS serves one wave's operations in program order, so the add of
+// slot i is visible to slot i + 1 without any barrier.
+template <int KPT>
+__device__ __forceinline__ void RankBallot(const uint32_t (&key)[KPT], uint32_t shift, uint32_t* myHist,
+                                           int lane, uint32_t (&rank)[KPT]) {
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) {
+    const uint32_t d = (key[i] >> shift) & 0xFFu;
+    const uint64_t same = (kAblate & 2u) ? (1ull << lane) : MatchDigit(d);
+    const uint32_t below = LanesBelow(same);
+    uint32_t prior = 0;
+    if (!(kAblate & 16u)) {
+      prior = __hip_atomic_load(&myHist[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (below == 0)
+        __hip_atomic_fetch_add(&myHist[d], (uint32_t)__popcll(same), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    rank[i] = prior + below;
+  }
+}
+
+template <int KPT>
+__device__ __forceinline__ void RankAtomic(const uint32_t (&key)[KPT], uint32_t shift, uint32_t* myHist,
+                                           int lane, uint32_t (&rank)[KPT]) {
+  bool uniform[KPT];
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) {
+    const uint32_t d = (key[i] >> shift) & 0xFFu;
+    const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+    uniform[i] = __ballot(d != d0) == 0ull;  // wave-uniform
+    uint32_t old = 0;
+    if (!uniform[i] || lane == 0)
+      old = __hip_atomic_fetch_add(&myHist[d], uniform[i] ? 64u : 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+    rank[i] = old;
+  }
+#pragma unroll
+  for (int i = 0; i < KPT; ++i)
+    if (uniform[i]) rank[i] = __builtin_amdgcn_readfirstlane(rank[i]) + lane;
+}
+
+template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK>
 __global__ __launch_bounds__(THREADS) void onesweep_kernel(OnesweepArgs a) {
   constexpr int WAVES = THREADS / 64;
   constexpr uint32_t TILE = THREADS * KPT;
@@ -213,7 +274,7 @@ __global__ __launch_bounds__(THREADS) void onesweep_kernel(OnesweepArgs a) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
 
-  if (tid == 0) misc[0] = atomicAdd(a.ticketCur, 1u);
+  if (tid == 0) misc[0] = (kAblate & 8u) ? blockIdx.x : atomicAdd(a.ticketCur, 1u);
   for (int i = tid; i < WAVES * 256; i += THREADS) waveHist[i] = 0;
   __syncthreads();
 
@@ -263,25 +324,12 @@ __global__ __launch_bounds__(THREADS) void onesweep_kernel(OnesweepArgs a) {
     }
   }
 
-  // ---- rank inside the wave: match-any ballots + a wave-private running digit counter ---------
-  // rank = (#same-digit keys of this wave in earlier slots) + (#same-digit lower lanes).  The
-  // counter read and the leader's add are issued back to back (the add does not depend on the
-  // read); LDS executes a wave's operations in order, so slot i+1 sees slot i's add.
+  // ---- rank inside the wave (memory order) ---------------------------------------------------
   uint32_t rank[KPT];
-  {
-    uint32_t* const myHist = waveHist + wave * 256;
-#pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-      const uint32_t d = (key[i] >> a.shift) & 0xFFu;
-      const uint64_t same = MatchDigit(d);
-      const uint32_t below = LanesBelow(same);
-      const uint32_t prior = __hip_atomic_load(&myHist[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (below == 0)
-        __hip_atomic_fetch_add(&myHist[d], (uint32_t)__popcll(same), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_WORKGROUP);
-      rank[i] = prior + below;
-    }
-  }
+  if (ATOMIC_RANK)
+    RankAtomic<KPT>(key, a.shift, waveHist + wave * 256, lane, rank);
+  else
+    RankBallot<KPT>(key, a.shift, waveHist + wave * 256, lane, rank);
   __syncthreads();
 
   // ---- tile histogram, aggregate publish, tile-local digit offsets ---------------------------
@@ -313,7 +361,8 @@ __global__ __launch_bounds__(THREADS) void onesweep_kernel(OnesweepArgs a) {
 
   // ---- decoupled look-back (threads 0..255, one digit each) while the other waves regroup -----
   if (tid < 256) {
-    const uint32_t exclusive = tile == 0 ? globalExclusive : LookBack(a.statusCur, tile, tid, a.failure);
+    const uint32_t exclusive =
+        (tile == 0 || (kAblate & 1u)) ? globalExclusive : LookBack(a.statusCur, tile, tid, a.failure);
     if (!lastTile)
       StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid],
                   (VRDX_FLAG_INCLUSIVE << VRDX_FLAG_SHIFT) | ((exclusive + count) & VRDX_VALUE_MASK));
@@ -325,6 +374,7 @@ __global__ __launch_bounds__(THREADS) void onesweep_kernel(OnesweepArgs a) {
   for (int i = 0; i < KPT; ++i) {
     const uint32_t d = (key[i] >> a.shift) & 0xFFu;
     rank[i] += waveHist[wave * 256 + d];  // now the tile-local sorted position
+    if (kAblate & (2u | 16u)) rank[i] = (rank[i] + i * 64 + wave * KPT * 64) % TILE;
     sorted[rank[i]] = key[i];
   }
   __syncthreads();
@@ -337,7 +387,7 @@ __global__ __launch_bounds__(THREADS) void onesweep_kernel(OnesweepArgs a) {
     if (p < valid) {
       const uint32_t k = sorted[p];
       const uint32_t d = (k >> a.shift) & 0xFFu;
-      const uint32_t o = tileOffset[d] + p;
+      const uint32_t o = (kAblate & 4u) ? tileStart + p : tileOffset[d] + p;
       a.keysOut[o] = k;
       if (KV) dst[j] = o;
     }
@@ -357,6 +407,38 @@ __global__ __launch_bounds__(THREADS) void onesweep_kernel(OnesweepArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// device self-check for RankAtomic's precondition
+// ---------------------------------------------------------------------------------------------
+// Every wave ranks pseudo-random digit vectors of several entropies (constant, 2, 4, 16, 256
+// distinct values, sparse collisions) both ways and counts disagreements.  16 waves per
+// workgroup hammer the LDS at the same time.
+__global__ __launch_bounds__(1024) void lds_order_check_kernel(uint32_t* mismatches) {
+  __shared__ uint32_t counters[2 * 16 * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 2 * 16 * 256; i += 1024) counters[i] = 0;
+  __syncthreads();
+  uint32_t* const histA = counters + wave * 256;
+  uint32_t* const histB = counters + (16 + wave) * 256;
+  uint32_t bad = 0;
+  for (uint32_t round = 0; round < 8; ++round) {
+    uint32_t key[8], ra[8], rb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      uint32_t x = (blockIdx.x * 1024u + tid) * 0x9E3779B9u + (round * 8 + i) * 0x85EBCA6Bu;
+      x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+      const uint32_t mode = (blockIdx.x + wave + round * 8 + i) % 6u;
+      const uint32_t mask = mode == 0 ? 0u : mode == 1 ? 1u : mode == 2 ? 3u : mode == 3 ? 15u : mode == 4 ? 0x21u : 255u;
+      key[i] = x & mask;
+    }
+    RankAtomic<8>(key, 0, histA, lane, ra);
+    RankBallot<8>(key, 0, histB, lane, rb);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bad += ra[i] != rb[i];
+  }
+  if (bad != 0) atomicAdd(mismatches, bad);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
 
@@ -368,20 +450,35 @@ static size_t OnesweepLdsBytes() {
 template <int THREADS, int KPT>
 static hipError_t PrepareConfig() {
   const int bytes = (int)OnesweepLdsBytes<THREADS, KPT>();
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, true>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  const void* kernels[4] = {
+      reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, false, false>),
+      reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, true, false>),
+      reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, false, true>),
+      reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, true, true>),
+  };
+  for (const void* k : kernels) {
+    const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 template <int THREADS, int KPT>
-static void LaunchConfig(hipStream_t stream, uint32_t grid, bool keyValue, const OnesweepArgs& args) {
+static void LaunchConfig(hipStream_t stream, uint32_t grid, bool keyValue, bool atomicRank,
+                         const OnesweepArgs& args) {
   const size_t lds = OnesweepLdsBytes<THREADS, KPT>();
-  if (keyValue)
-    hipLaunchKernelGGL((onesweep_kernel<THREADS, KPT, true>), dim3(grid), dim3(THREADS), lds, stream, args);
-  else
-    hipLaunchKernelGGL((onesweep_kernel<THREADS, KPT, false>), dim3(grid), dim3(THREADS), lds, stream, args);
+  const dim3 g(grid), b(THREADS);
+  if (keyValue) {
+    if (atomicRank)
+      hipLaunchKernelGGL((onesweep_kernel<THREADS, KPT, true, true>), g, b, lds, stream, args);
+    else
+      hipLaunchKernelGGL((onesweep_kernel<THREADS, KPT, true, false>), g, b, lds, stream, args);
+  } else {
+    if (atomicRank)
+      hipLaunchKernelGGL((onesweep_kernel<THREADS, KPT, false, true>), g, b, lds, stream, args);
+    else
+      hipLaunchKernelGGL((onesweep_kernel<THREADS, KPT, false, false>), g, b, lds, stream, args);
+  }
 }
 
 const TileConfig kTileConfigs[kNumTileConfigs] = {
@@ -399,20 +496,35 @@ hipError_t PrepareKernels(int configIndex) {
   }
 }
 
+hipError_t LdsOrderCheck(bool* laneOrdered) {
+  uint32_t* d = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d), sizeof(uint32_t));
+  if (e != hipSuccess) return e;
+  uint32_t h = 0xFFFFFFFFu;
+  e = hipMemset(d, 0, sizeof(uint32_t));
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(lds_order_check_kernel, dim3(512), dim3(1024), 0, nullptr, d);
+    e = hipMemcpy(&h, d, sizeof(uint32_t), hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(d);
+  if (e == hipSuccess) *laneOrdered = h == 0;
+  return e;
+}
+
 void LaunchHistogram(hipStream_t stream, uint32_t grid, const uint32_t* keys, uint32_t maxCount,
                      const uint32_t* countPtr, uint32_t* globalHistogram) {
   hipLaunchKernelGGL(histogram_kernel, dim3(grid), dim3(kHistThreads), 0, stream, keys, maxCount, countPtr,
                      globalHistogram);
 }
 
-void LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool keyValue,
+void LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool keyValue, bool atomicRank,
                     const OnesweepArgs& args) {
   switch (configIndex) {
-    case 0: LaunchConfig<512, 16>(stream, grid, keyValue, args); break;
-    case 1: LaunchConfig<1024, 16>(stream, grid, keyValue, args); break;
-    case 2: LaunchConfig<512, 32>(stream, grid, keyValue, args); break;
-    case 3: LaunchConfig<1024, 8>(stream, grid, keyValue, args); break;
-    case 4: LaunchConfig<256, 32>(stream, grid, keyValue, args); break;
+    case 0: LaunchConfig<512, 16>(stream, grid, keyValue, atomicRank, args); break;
+    case 1: LaunchConfig<1024, 16>(stream, grid, keyValue, atomicRank, args); break;
+    case 2: LaunchConfig<512, 32>(stream, grid, keyValue, atomicRank, args); break;
+    case 3: LaunchConfig<1024, 8>(stream, grid, keyValue, atomicRank, args); break;
+    case 4: LaunchConfig<256, 32>(stream, grid, keyValue, atomicRank, args); break;
     default: break;
   }
 }
