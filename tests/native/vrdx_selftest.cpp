@@ -392,6 +392,28 @@ int main(int argc, char** argv) {
   h.init();
   std::printf("%s\n", vrdxHipVersionString());
   if (what == "parity" || what == "quick") return Parity(h, what == "quick") ? 1 : 0;
+  if (what == "trace") {  // one sort, for tools/trace.sh (stamps are dumped by vrdxDestroySorter)
+    const uint32_t n = 1u << (argc > 2 ? std::atoi(argv[2]) : 25);
+    const bool kv = argc > 3 && std::string(argv[3]) == "kv";
+    VrdxSorterStorageRequirements req;
+    vrdxGetSorterKeyValueStorageRequirements(h.sorter, n, &req);
+    const uint32_t inout = Align16(n * 4u);
+    h.reserve((size_t)2 * inout + 16, (size_t)req.size);
+    for (int rep = 0; rep < 3; ++rep) {
+      std::vector<uint32_t> v;
+      auto k = Mt(n, rep + 1, 32, &v);
+      HIP_OK(hipMemcpy(h.dKeys, k.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+      HIP_OK(hipMemcpy(h.dKeys + inout, v.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+      if (kv)
+        vrdxCmdSortKeyValue((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dKeys, inout,
+                            (VkBuffer)h.dStorage, 0, VK_NULL_HANDLE, 0);
+      else
+        vrdxCmdSort((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dStorage, 0, VK_NULL_HANDLE, 0);
+      HIP_OK(hipStreamSynchronize(h.stream));
+    }
+    vrdxDestroySorter(h.sorter);
+    return 0;
+  }
   if (what == "bench") {
     std::vector<int> logs;
     for (int i = 2; i < argc; ++i) logs.push_back(std::atoi(argv[i]));

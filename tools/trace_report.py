@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Summarises a VRDX_TRACE dump (tools/trace.sh): per pass, per phase durations in microseconds."""
+import struct
+import sys
+
+import numpy as np
+
+PHASES = ["ticket", "load+rank", "hist/scan", "regroup", "look-back", "scatter"]
+
+
+def main(path):
+    raw = open(path, "rb").read()
+    tiles = struct.unpack_from("<I", raw, 0)[0]
+    data = np.frombuffer(raw, dtype=np.uint64, offset=4).reshape(4, tiles, 8)
+    for p in range(4):
+        t = data[p, :, :7].astype(np.int64)
+        t0 = t[:, 0].min()
+        rel = (t - t0) / 100.0  # 100 MHz wall clock -> microseconds
+        dur = np.diff(rel, axis=1)
+        total = rel[:, 6] - rel[:, 0]
+        print(f"pass {p}: tiles {tiles}  span {rel[:, 6].max():.1f} us  tile life mean {total.mean():.2f} "
+              f"p50 {np.median(total):.2f} p95 {np.percentile(total, 95):.2f} us")
+        for i, name in enumerate(PHASES):
+            c = dur[:, i]
+            print(f"    {name:10s} mean {c.mean():7.2f}  p50 {np.median(c):7.2f}  p95 {np.percentile(c, 95):7.2f}  "
+                  f"max {c.max():7.2f}  sum/span {c.sum() / rel[:, 6].max():7.1f}")
+        # concurrency and start profile
+        starts = np.sort(rel[:, 0])
+        print("    tile start times (us) at 10% steps:", " ".join(f"{starts[int(q * (tiles - 1))]:.1f}" for q in np.linspace(0, 1, 11)))
+        order = np.argsort(rel[:, 0])
+        first = order[: min(600, tiles)]
+        lb = dur[:, 4]
+        print(f"    look-back of the first {len(first)} started tiles: mean {lb[first].mean():.2f} max {lb[first].max():.2f};"
+              f" of the rest: mean {np.delete(lb, first).mean() if tiles > len(first) else 0:.2f}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

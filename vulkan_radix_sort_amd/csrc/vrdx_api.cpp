@@ -57,6 +57,40 @@ int DefaultConfigIndex() {
   return 0;
 }
 
+#ifdef VRDX_TRACE
+// tools/trace.sh only: one device buffer of 8 stamps per (pass, tile), dumped to $VRDX_TRACE_FILE
+// by vrdxDestroySorter.  Holds the LAST sort recorded before the dump.
+unsigned long long* g_trace = nullptr;
+uint32_t g_traceTiles = 0;
+constexpr uint32_t kTraceMaxTiles = 1u << 16;
+unsigned long long* TraceBuffer(uint32_t pass, uint32_t tiles) {
+  if (g_trace == nullptr) {
+    if (hipMalloc(reinterpret_cast<void**>(&g_trace), 4ull * kTraceMaxTiles * 8 * sizeof(unsigned long long)) !=
+        hipSuccess)
+      return nullptr;
+  }
+  if (tiles > kTraceMaxTiles) return nullptr;
+  g_traceTiles = tiles;
+  return g_trace + (size_t)pass * kTraceMaxTiles * 8;
+}
+void DumpTrace() {
+  const char* path = std::getenv("VRDX_TRACE_FILE");
+  if (g_trace == nullptr || path == nullptr) return;
+  (void)hipDeviceSynchronize();
+  const size_t words = 4ull * kTraceMaxTiles * 8;
+  unsigned long long* host = new unsigned long long[words];
+  if (hipMemcpy(host, g_trace, words * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+    if (FILE* f = std::fopen(path, "wb")) {
+      std::fwrite(&g_traceTiles, sizeof(g_traceTiles), 1, f);
+      for (uint32_t pass = 0; pass < 4; ++pass)
+        std::fwrite(host + (size_t)pass * kTraceMaxTiles * 8, sizeof(unsigned long long), (size_t)g_traceTiles * 8, f);
+      std::fclose(f);
+    }
+  }
+  delete[] host;
+}
+#endif
+
 inline uint8_t* BufferAddress(VkBuffer buffer, VkDeviceSize offset) {
   return reinterpret_cast<uint8_t*>(buffer) + offset;
 }
@@ -144,6 +178,10 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     args.ticketNext = tickets + ((pass + 1) & 1u);
     args.failure = failure;
     args.shift = 8 * pass;
+    args.trace = nullptr;
+#ifdef VRDX_TRACE
+    args.trace = TraceBuffer(pass, tiles);
+#endif
     vrdx::LaunchOnesweep(stream, sorter->configIndex, tiles, keyValue, sorter->atomicRank, args);
 
     Stamp(pool, query + 2 + 3 * pass + 2, stream);  // "downsweep"
@@ -210,6 +248,9 @@ VkResult vrdxCreateSorter(const VrdxSorterCreateInfo* pCreateInfo, VrdxSorter* p
 
 void vrdxDestroySorter(VrdxSorter sorter) {
   if (sorter == nullptr) return;  // reference :268
+#ifdef VRDX_TRACE
+  DumpTrace();
+#endif
   delete sorter;
 }
 

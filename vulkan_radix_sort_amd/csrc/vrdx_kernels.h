@@ -36,6 +36,7 @@ struct OnesweepArgs {
   uint32_t* ticketNext;
   uint32_t* failure;
   uint32_t shift;             // 8 * pass
+  unsigned long long* trace;  // phase stamps, 8 per tile; nullptr outside tools/trace.sh builds
 };
 
 // Raises the dynamic-LDS limit of both instantiations (keys-only, key-value) of one tile config.

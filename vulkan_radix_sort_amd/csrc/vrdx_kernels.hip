@@ -33,6 +33,19 @@ namespace vrdx {
 #endif
 constexpr uint32_t kAblate = VRDX_ABLATE;
 
+// Timing-only phase trace for tools/trace.sh (never defined in the product build): thread 0 of
+// every tile stores 100 MHz wall-clock stamps of its phase boundaries into OnesweepArgs::trace.
+#ifdef VRDX_TRACE
+#define VRDX_STAMP(slot)                                      \
+  do {                                                        \
+    if (a.trace != nullptr && tid == 0) stamps[slot] = wall_clock64(); \
+  } while (0)
+#else
+#define VRDX_STAMP(slot) \
+  do {                   \
+  } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------
@@ -157,49 +170,92 @@ __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t*
 // onesweep: rank + decoupled look-back + scatter, one launch per pass
 // ---------------------------------------------------------------------------------------------
 
-// Thread `digit` of tile `tile` sums the counts of the preceding tiles until it meets an inclusive
-// prefix.  kWindow status words are requested per trip so that their latencies overlap.
-__device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t tile, uint32_t digit,
+// Decoupled look-back by the WHOLE workgroup.  Thread (g, d) = (tid / 256, tid % 256) inspects
+// kLookBackWindow consecutive predecessor tiles of digit d per trip, group g starting where group
+// g - 1 ends, so one trip covers GROUPS * kLookBackWindow tiles with every status load in flight at
+// once.  (At the start of a pass all resident tiles begin together and the inclusive prefixes
+// spread tile by tile; the number of trips a tile needs falls with the square root of the
+// window, which is why the window is wide.)  Group 0's thread of each digit then stitches the
+// groups' partial sums together in order.  Returns the exclusive prefix in the threads tid < 256.
+//
+// lds: pos[256] | sum[GROUPS][256] | info[GROUPS][256]   (info = consumed | hitInclusive << 8)
+constexpr int kLookBackWindow = 16;
+constexpr uint32_t kSpinLimit = 1u << 18;
+constexpr int32_t kLookBackDone = INT32_MIN;
+
+template <int THREADS>
+__device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t tile, int tid, uint32_t* lds,
                                              uint32_t* failure) {
-  constexpr int kWindow = 8;
-  constexpr uint32_t kSpinLimit = 1u << 20;
+  constexpr int GROUPS = THREADS / 256;
+  constexpr int W = kLookBackWindow;
+  int32_t* const pos = reinterpret_cast<int32_t*>(lds);
+  uint32_t* const sum = lds + 256;
+  uint32_t* const info = sum + GROUPS * 256;
+  const int g = tid >> 8;
+  const int d = tid & 255;
+
   uint32_t exclusive = 0;
-  int32_t j = (int32_t)tile - 1;
   uint32_t spins = 0;
-  bool done = false;
-  while (!done) {
-    uint32_t v[kWindow];
+  bool done = g != 0;  // only group 0 owns the per-digit state
+  if (g == 0) pos[d] = (int32_t)tile - 1;
+  __syncthreads();
+
+  for (;;) {
+    const int32_t j = pos[d];
+    if (j != kLookBackDone) {
+      const int32_t first = j - g * W;
+      uint32_t v[W];
 #pragma unroll
-    for (int k = 0; k < kWindow; ++k) {
-      const int32_t jj = j - k;
-      v[k] = jj >= 0 ? LoadStatus(&status[(uint32_t)jj * VRDX_RADIX + digit])
-                     : (VRDX_FLAG_INCLUSIVE << VRDX_FLAG_SHIFT);
-    }
-    bool open = true;
-    int consumed = 0;
+      for (int k = 0; k < W; ++k) {
+        const int32_t row = first - k;
+        v[k] = row >= 0 ? LoadStatus(&status[(uint32_t)row * VRDX_RADIX + d])
+                        : (VRDX_FLAG_INCLUSIVE << VRDX_FLAG_SHIFT);
+      }
+      uint32_t partial = 0, consumed = 0, hit = 0;
+      bool open = true;
 #pragma unroll
-    for (int k = 0; k < kWindow; ++k) {
-      const uint32_t flag = v[k] >> VRDX_FLAG_SHIFT;
-      if (open && flag != VRDX_FLAG_EMPTY) {
-        exclusive += v[k] & VRDX_VALUE_MASK;
-        ++consumed;
-        if (flag == VRDX_FLAG_INCLUSIVE) {
-          done = true;
-          open = false;
+      for (int k = 0; k < W; ++k) {
+        const uint32_t flag = v[k] >> VRDX_FLAG_SHIFT;
+        open = open && flag != VRDX_FLAG_EMPTY;
+        if (open) {
+          partial += v[k] & VRDX_VALUE_MASK;
+          ++consumed;
+          if (flag == VRDX_FLAG_INCLUSIVE) {
+            hit = 1;
+            open = false;
+          }
         }
-      } else {
-        open = false;
       }
+      sum[g * 256 + d] = partial;
+      info[g * 256 + d] = consumed | (hit << 8);
     }
-    j -= consumed;
-    if (!done && consumed == 0) {
-      if (++spins > kSpinLimit) {
-        atomicOr(failure, 1u);
-        done = true;
-      } else {
-        __builtin_amdgcn_s_sleep(2);
+    __syncthreads();
+    if (g == 0 && !done) {
+      uint32_t advance = 0;
+#pragma unroll
+      for (int gg = 0; gg < GROUPS; ++gg) {
+        const uint32_t in = info[gg * 256 + d];
+        exclusive += sum[gg * 256 + d];
+        advance += in & 0xFFu;
+        if (in >> 8) {
+          done = true;
+          break;
+        }
+        if ((in & 0xFFu) < (uint32_t)W) break;  // blocked on a tile that has not published yet
       }
+      if (!done && advance == 0) {
+        if (++spins > kSpinLimit) {
+          atomicOr(failure, 1u);  // bounded: give up (result unspecified) rather than hang the GPU
+          done = true;
+        } else {
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      pos[d] = done ? kLookBackDone : j - (int32_t)advance;
     }
+    // One barrier + vote: this trip's sum/info are consumed and pos is updated before the next
+    // trip touches them.
+    if (__syncthreads_and(done ? 1 : 0)) break;
   }
   return exclusive;
 }
@@ -257,26 +313,40 @@ __device__ __forceinline__ void RankAtomic(const uint32_t (&key)[KPT], uint32_t 
     if (uniform[i]) rank[i] = __builtin_amdgcn_readfirstlane(rank[i]) + lane;
 }
 
+template <int THREADS, int KPT, bool KV>
+constexpr size_t OnesweepLdsWords() {
+  // sorted keys (+ sorted values) | per-wave digit counters (later: look-back scratch) |
+  // per-digit scatter offsets | scan scratch + ticket
+  return (size_t)THREADS * KPT * (KV ? 2 : 1) + (size_t)(THREADS / 64) * 256 + 256 + 16;
+}
+
 template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK>
 __global__ __launch_bounds__(THREADS) void onesweep_kernel(OnesweepArgs a) {
   constexpr int WAVES = THREADS / 64;
   constexpr uint32_t TILE = THREADS * KPT;
-  static_assert(THREADS >= 256 && THREADS % 64 == 0, "one thread per digit for the tile scan");
+  static_assert(THREADS >= 256 && THREADS % 256 == 0, "one thread per digit, whole look-back groups");
+  static_assert(WAVES * 256 >= 256 * (1 + 2 * (THREADS / 256)), "look-back scratch aliases the wave counters");
 
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  uint32_t* const sorted = smem;                          // TILE words: keys (then values) regrouped by digit
-  uint32_t* const waveHist = smem + TILE;                 // WAVES x 256
-  uint32_t* const tileOffset = waveHist + WAVES * 256;    // 256: global base - tile-local base, per digit
-  uint32_t* const scanScratch = tileOffset + 256;         // 8
-  uint32_t* const misc = scanScratch + 8;                 // [0] ticket
+  uint32_t* const sortedKeys = smem;                                // TILE: keys regrouped by digit
+  uint32_t* const sortedValues = smem + TILE;                       // TILE (KV only)
+  uint32_t* const waveHist = smem + (KV ? 2 : 1) * TILE;            // WAVES x 256, then look-back scratch
+  uint32_t* const tileOffset = waveHist + WAVES * 256;              // 256: global base - tile-local base
+  uint32_t* const scanScratch = tileOffset + 256;                   // 8
+  uint32_t* const misc = scanScratch + 8;                           // [0] ticket
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+#ifdef VRDX_TRACE
+  uint64_t stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  VRDX_STAMP(0);
 
   if (tid == 0) misc[0] = (kAblate & 8u) ? blockIdx.x : atomicAdd(a.ticketCur, 1u);
   for (int i = tid; i < WAVES * 256; i += THREADS) waveHist[i] = 0;
   __syncthreads();
+  VRDX_STAMP(1);
 
   const uint32_t tile = misc[0];
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
@@ -331,6 +401,7 @@ __global__ __launch_bounds__(THREADS) void onesweep_kernel(OnesweepArgs a) {
   else
     RankBallot<KPT>(key, a.shift, waveHist + wave * 256, lane, rank);
   __syncthreads();
+  VRDX_STAMP(2);
 
   // ---- tile histogram, aggregate publish, tile-local digit offsets ---------------------------
   uint32_t count = 0;
@@ -342,11 +413,11 @@ __global__ __launch_bounds__(THREADS) void onesweep_kernel(OnesweepArgs a) {
       StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid], (VRDX_FLAG_AGGREGATE << VRDX_FLAG_SHIFT) | count);
   }
   const uint32_t tileExclusive = BlockExclusiveScan256(tid < 256 ? count : 0u, scanScratch, tid);
-  uint32_t globalExclusive = 0;
+  uint32_t exclusive = 0;
   if (tile == 0) {
     // spine.slang:62-83 equivalent: exclusive scan of this pass's 256 global digit counts.
     const uint32_t g = tid < 256 ? a.globalHistogram[tid] : 0u;
-    globalExclusive = BlockExclusiveScan256(g, scanScratch + 4, tid);
+    exclusive = BlockExclusiveScan256(g, scanScratch + 4, tid);
   }
   if (tid < 256) {
     uint32_t run = tileExclusive;
@@ -358,52 +429,52 @@ __global__ __launch_bounds__(THREADS) void onesweep_kernel(OnesweepArgs a) {
     }
   }
   __syncthreads();
+  VRDX_STAMP(3);
 
-  // ---- decoupled look-back (threads 0..255, one digit each) while the other waves regroup -----
+  // ---- regroup keys (and values) by digit in LDS; registers are free afterwards --------------
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) {
+    const uint32_t d = (key[i] >> a.shift) & 0xFFu;
+    uint32_t p = rank[i] + waveHist[wave * 256 + d];  // tile-local sorted position
+    if (kAblate & (2u | 16u)) p = (p + i * 64 + wave * KPT * 64) % TILE;
+    sortedKeys[p] = key[i];
+    if (KV) sortedValues[p] = val[i];
+  }
+  __syncthreads();  // waveHist is dead from here on: the look-back reuses it as scratch
+  VRDX_STAMP(4);
+
+  // ---- decoupled look-back over the preceding tiles, then publish the inclusive prefix --------
+  if (tile != 0 && !(kAblate & 1u)) exclusive = LookBack<THREADS>(a.statusCur, tile, tid, waveHist, a.failure);
   if (tid < 256) {
-    const uint32_t exclusive =
-        (tile == 0 || (kAblate & 1u)) ? globalExclusive : LookBack(a.statusCur, tile, tid, a.failure);
     if (!lastTile)
       StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid],
                   (VRDX_FLAG_INCLUSIVE << VRDX_FLAG_SHIFT) | ((exclusive + count) & VRDX_VALUE_MASK));
     tileOffset[tid] = exclusive - tileExclusive;
   }
-
-  // ---- regroup keys by digit in LDS ----------------------------------------------------------
-#pragma unroll
-  for (int i = 0; i < KPT; ++i) {
-    const uint32_t d = (key[i] >> a.shift) & 0xFFu;
-    rank[i] += waveHist[wave * 256 + d];  // now the tile-local sorted position
-    if (kAblate & (2u | 16u)) rank[i] = (rank[i] + i * 64 + wave * KPT * 64) % TILE;
-    sorted[rank[i]] = key[i];
-  }
   __syncthreads();
+  VRDX_STAMP(5);
 
   // ---- scatter: consecutive lanes -> consecutive addresses inside each digit run --------------
-  uint32_t dst[KV ? KPT : 1];
 #pragma unroll
   for (int j = 0; j < KPT; ++j) {
     const uint32_t p = tid + j * THREADS;
     if (p < valid) {
-      const uint32_t k = sorted[p];
+      const uint32_t k = sortedKeys[p];
       const uint32_t d = (k >> a.shift) & 0xFFu;
       const uint32_t o = (kAblate & 4u) ? tileStart + p : tileOffset[d] + p;
       a.keysOut[o] = k;
-      if (KV) dst[j] = o;
+      if (KV) a.valuesOut[o] = sortedValues[p];
     }
   }
-
-  if (KV) {
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < KPT; ++i) sorted[rank[i]] = val[i];
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < KPT; ++j) {
-      const uint32_t p = tid + j * THREADS;
-      if (p < valid) a.valuesOut[dst[j]] = sorted[p];
-    }
+#ifdef VRDX_TRACE
+  VRDX_STAMP(6);
+  if (a.trace != nullptr && tid == 0) {
+    uint32_t xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    stamps[7] = ((uint64_t)(xcc & 0xF) << 32) | blockIdx.x;
+    for (int i = 0; i < 8; ++i) a.trace[(size_t)tile * 8 + i] = stamps[i];
   }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -443,21 +514,20 @@ __global__ __launch_bounds__(1024) void lds_order_check_kernel(uint32_t* mismatc
 // ---------------------------------------------------------------------------------------------
 
 template <int THREADS, int KPT>
-static size_t OnesweepLdsBytes() {
-  return ((size_t)THREADS * KPT + (THREADS / 64) * 256 + 256 + 8 + 4) * sizeof(uint32_t);
-}
-
-template <int THREADS, int KPT>
 static hipError_t PrepareConfig() {
-  const int bytes = (int)OnesweepLdsBytes<THREADS, KPT>();
-  const void* kernels[4] = {
-      reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, false, false>),
-      reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, true, false>),
-      reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, false, true>),
-      reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, true, true>),
+  const int keysBytes = (int)(OnesweepLdsWords<THREADS, KPT, false>() * sizeof(uint32_t));
+  const int kvBytes = (int)(OnesweepLdsWords<THREADS, KPT, true>() * sizeof(uint32_t));
+  const struct {
+    const void* fn;
+    int bytes;
+  } kernels[4] = {
+      {reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, false, false>), keysBytes},
+      {reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, false, true>), keysBytes},
+      {reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, true, false>), kvBytes},
+      {reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, true, true>), kvBytes},
   };
-  for (const void* k : kernels) {
-    const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  for (const auto& k : kernels) {
+    const hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, k.bytes);
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
@@ -466,7 +536,8 @@ static hipError_t PrepareConfig() {
 template <int THREADS, int KPT>
 static void LaunchConfig(hipStream_t stream, uint32_t grid, bool keyValue, bool atomicRank,
                          const OnesweepArgs& args) {
-  const size_t lds = OnesweepLdsBytes<THREADS, KPT>();
+  const size_t lds = (keyValue ? OnesweepLdsWords<THREADS, KPT, true>() : OnesweepLdsWords<THREADS, KPT, false>()) *
+                     sizeof(uint32_t);
   const dim3 g(grid), b(THREADS);
   if (keyValue) {
     if (atomicRank)
