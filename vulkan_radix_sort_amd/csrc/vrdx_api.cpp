@@ -22,8 +22,8 @@
 struct VrdxSorter_T {
   int device = 0;
   int computeUnits = 0;
-  int configIndex = 0;
-  uint32_t tileKeys = 0;
+  int configKeys = 0;      // tile geometry of the keys-only kernels
+  int configKeyValue = 0;  // tile geometry of the key+value kernels
   bool atomicRank = false;  // LDS returning atomics proven lane-ordered on this device
   // reference: VrdxSorter_T::minStorageBufferOffsetAlignment (src/vk_radix_sort.h.in:134)
   uint32_t minStorageBufferOffsetAlignment = VRDX_STORAGE_ALIGN;
@@ -43,8 +43,13 @@ int DeviceOrdinalFromHandle(const void* handle, int* ordinal) {
   return 0;
 }
 
-int DefaultConfigIndex() {
-  const char* env = std::getenv("VRDX_TILE_CONFIG");  // e.g. "512x16"; tuning/testing knob
+// Measured on MI355X at N = 2^25 (profiles/): keys-only is fastest with 16384-key tiles of 512
+// threads (2 workgroups per CU), key+value with 16384-key tiles of 1024 threads.
+constexpr int kDefaultConfigKeys = 2;      // 512 x 32
+constexpr int kDefaultConfigKeyValue = 1;  // 1024 x 16
+
+int ConfigIndex(bool keyValue) {
+  const char* env = std::getenv("VRDX_TILE_CONFIG");  // e.g. "512x16": overrides both; tuning/testing knob
   if (env != nullptr) {
     for (int i = 0; i < vrdx::kNumTileConfigs; ++i) {
       char name[32];
@@ -54,7 +59,7 @@ int DefaultConfigIndex() {
     }
     std::fprintf(stderr, "vrdx-hip: unknown VRDX_TILE_CONFIG '%s', using default\n", env);
   }
-  return 0;
+  return keyValue ? kDefaultConfigKeyValue : kDefaultConfigKeys;
 }
 
 #ifdef VRDX_TRACE
@@ -111,8 +116,10 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   const bool keyValue = valuesBuffer != nullptr;
   if (elementCount > VRDX_MAX_ELEMENTS) elementCount = VRDX_MAX_ELEMENTS;
 
+  const int configIndex = keyValue ? sorter->configKeyValue : sorter->configKeys;
+  const uint32_t tileKeys = vrdx::kTileConfigs[configIndex].tileKeys();
   const vrdx::StorageLayout layout =
-      vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, sorter->tileKeys);
+      vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, tileKeys);
   uint8_t* const storage = BufferAddress(storageBuffer, storageOffset);
   uint32_t* const keys = reinterpret_cast<uint32_t*>(BufferAddress(keysBuffer, keysOffset));
   uint32_t* const values =
@@ -155,7 +162,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     vrdx::LaunchHistogram(stream, grid, keys, elementCount, countPtr, globalHistogram);
   }
 
-  const uint32_t tiles = vrdx::RoundUp(elementCount, sorter->tileKeys);
+  const uint32_t tiles = vrdx::RoundUp(elementCount, tileKeys);
   for (uint32_t pass = 0; pass < VRDX_PASSES; ++pass) {
     Stamp(pool, query + 2 + 3 * pass + 0, stream);  // "upsweep" of this pass
     Stamp(pool, query + 2 + 3 * pass + 1, stream);  // "spine" (fused into the onesweep look-back)
@@ -182,7 +189,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
 #ifdef VRDX_TRACE
     args.trace = TraceBuffer(pass, tiles);
 #endif
-    vrdx::LaunchOnesweep(stream, sorter->configIndex, tiles, keyValue, sorter->atomicRank, args);
+    vrdx::LaunchOnesweep(stream, configIndex, tiles, keyValue, sorter->atomicRank, args);
 
     Stamp(pool, query + 2 + 3 * pass + 2, stream);  // "downsweep"
   }
@@ -215,13 +222,14 @@ VkResult vrdxCreateSorter(const VrdxSorterCreateInfo* pCreateInfo, VrdxSorter* p
   if (sorter == nullptr) return VK_ERROR_OUT_OF_HOST_MEMORY;
   sorter->device = ordinal;
   sorter->computeUnits = prop.multiProcessorCount;
-  sorter->configIndex = DefaultConfigIndex();
-  sorter->tileKeys = vrdx::kTileConfigs[sorter->configIndex].tileKeys();
+  sorter->configKeys = ConfigIndex(false);
+  sorter->configKeyValue = ConfigIndex(true);
 
   int previous = 0;
   (void)hipGetDevice(&previous);
   hipError_t e = hipSetDevice(ordinal);
-  if (e == hipSuccess) e = vrdx::PrepareKernels(sorter->configIndex);
+  if (e == hipSuccess) e = vrdx::PrepareKernels(sorter->configKeys);
+  if (e == hipSuccess) e = vrdx::PrepareKernels(sorter->configKeyValue);
   if (e == hipSuccess) {
     // Ranking mode: the single-atomic form needs a hardware property the ISA manual does not
     // promise, so it is verified here, once, on this very device; VRDX_RANK=ballot|atomic|auto.
@@ -256,16 +264,16 @@ void vrdxDestroySorter(VrdxSorter sorter) {
 
 void vrdxGetSorterStorageRequirements(VrdxSorter sorter, uint32_t maxElementCount,
                                       VrdxSorterStorageRequirements* requirements) {
-  const vrdx::StorageLayout layout =
-      vrdx::MakeLayout(maxElementCount, sorter->minStorageBufferOffsetAlignment, sorter->tileKeys);
+  const vrdx::StorageLayout layout = vrdx::MakeLayout(maxElementCount, sorter->minStorageBufferOffsetAlignment,
+                                                      vrdx::kTileConfigs[sorter->configKeys].tileKeys());
   requirements->size = layout.keysOnlySize;
   requirements->usage = VK_BUFFER_USAGE_STORAGE_BUFFER_BIT | VK_BUFFER_USAGE_TRANSFER_DST_BIT;
 }
 
 void vrdxGetSorterKeyValueStorageRequirements(VrdxSorter sorter, uint32_t maxElementCount,
                                               VrdxSorterStorageRequirements* requirements) {
-  const vrdx::StorageLayout layout =
-      vrdx::MakeLayout(maxElementCount, sorter->minStorageBufferOffsetAlignment, sorter->tileKeys);
+  const vrdx::StorageLayout layout = vrdx::MakeLayout(maxElementCount, sorter->minStorageBufferOffsetAlignment,
+                                                      vrdx::kTileConfigs[sorter->configKeyValue].tileKeys());
   requirements->size = layout.keyValueSize;
   requirements->usage = VK_BUFFER_USAGE_STORAGE_BUFFER_BIT | VK_BUFFER_USAGE_TRANSFER_DST_BIT;
 }
@@ -369,10 +377,11 @@ uint32_t vrdxHipReadStatus(VkCommandBuffer commandBuffer, VkBuffer storageBuffer
 }
 
 const char* vrdxHipVersionString(void) {
-  static char text[96];
-  const int idx = DefaultConfigIndex();
-  std::snprintf(text, sizeof(text), "vrdx-hip %d.%d.%d gfx950 tile=%u", VRDX_VERSION_MAJOR,
-                VRDX_VERSION_MINOR, VRDX_VERSION_PATCH, vrdx::kTileConfigs[idx].tileKeys());
+  static char text[128];
+  const vrdx::TileConfig& k = vrdx::kTileConfigs[ConfigIndex(false)];
+  const vrdx::TileConfig& kv = vrdx::kTileConfigs[ConfigIndex(true)];
+  std::snprintf(text, sizeof(text), "vrdx-hip %d.%d.%d gfx950 tile keys=%dx%d key-value=%dx%d", VRDX_VERSION_MAJOR,
+                VRDX_VERSION_MINOR, VRDX_VERSION_PATCH, k.threads, k.keysPerThread, kv.threads, kv.keysPerThread);
   return text;
 }
 

@@ -179,7 +179,10 @@ __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t*
 // groups' partial sums together in order.  Returns the exclusive prefix in the threads tid < 256.
 //
 // lds: pos[256] | sum[GROUPS][256] | info[GROUPS][256]   (info = consumed | hitInclusive << 8)
-constexpr int kLookBackWindow = 16;
+#ifndef VRDX_LOOKBACK_WINDOW
+#define VRDX_LOOKBACK_WINDOW 8
+#endif
+constexpr int kLookBackWindow = VRDX_LOOKBACK_WINDOW;
 constexpr uint32_t kSpinLimit = 1u << 18;
 constexpr int32_t kLookBackDone = INT32_MIN;
 
