@@ -269,28 +269,33 @@ def test_sorts_on_a_side_stream_and_two_sorters_concurrently(torch_mod, oracle):
 
 
 def test_capturable_into_a_hip_graph(torch_mod, sorter, oracle):
-    # VkCommandBuffer == stream-ordered enqueue: recording inside a stream capture must work
+    # VkCommandBuffer == stream-ordered enqueue: recording inside a stream capture must work.
+    # tests/native/vrdx_selftest checks this with the bare HIP graph API (hipStreamBeginCapture ->
+    # vrdxCmdSort* -> hipGraphLaunch) on a cold process.  Through torch.cuda.CUDAGraph the replay was
+    # observed to be a silent no-op when the FIRST launch of the sort kernels in the process
+    # happened inside the capture, so one eager sort runs first (as any real caller has done).
     torch = torch_mod
     n = 200000
     k, v = oracle.generate(31, n, 32)
     dk, dv = _u32_to_dev(torch, k), _u32_to_dev(torch, v)
     storage = torch.empty(sorter.key_value_storage_requirements(n).size, dtype=torch.uint8, device="cuda")
+    warm_k, warm_v = _u32_to_dev(torch, k), _u32_to_dev(torch, v)
+    sorter.cmd_sort_key_value(torch.cuda.current_stream().cuda_stream, n, warm_k.data_ptr(), 0, warm_v.data_ptr(), 0,
+                              storage.data_ptr(), 0)
+    torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        g.capture_begin()
+    with torch.cuda.graph(g):
         sorter.cmd_sort_key_value(torch.cuda.current_stream().cuda_stream, n, dk.data_ptr(), 0, dv.data_ptr(), 0,
                                   storage.data_ptr(), 0)
-        g.capture_end()
-    torch.cuda.current_stream().wait_stream(side)
     ek, ev, _ = oracle.sort(k, v)
-    for _ in range(2):  # replay twice: second replay sorts already-sorted data
+    for _ in range(2):  # replay twice: fresh unsorted input each time
         dk.copy_(_u32_to_dev(torch, k))
         dv.copy_(_u32_to_dev(torch, v))
+        torch.cuda.synchronize()
         g.replay()
         torch.cuda.synchronize()
         assert np.array_equal(_to_u32(dk), ek) and np.array_equal(_to_u32(dv), ev)
+        assert sorter.read_status(torch.cuda.current_stream().cuda_stream, storage.data_ptr(), 0) == 0
 
 
 @pytest.mark.parametrize("seed", [1, 2])

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Turns rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/probes/pmc_calibrate into HBM bytes
+per launch for the sort kernels, calibrated on the copy kernels of the same run.
+
+    python tools/pmc_report.py <fetch_counter_collection.csv> <write_counter_collection.csv> N [out.json]
+"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def per_kernel(path, counter):
+    acc = defaultdict(list)
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row.get("Counter_Name") != counter:
+                continue
+            acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+def pick(d, needle):
+    for k, v in d.items():
+        if needle in k:
+            return v
+    raise KeyError(needle)
+
+
+def main():
+    fetch_csv, write_csv, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    fetch, calls = per_kernel(fetch_csv, "FETCH_SIZE")
+    write, _ = per_kernel(write_csv, "WRITE_SIZE")
+    known = 4.0 * n
+    f4 = known / pick(fetch, "copy_dword")      # bytes per FETCH_SIZE unit, 4 B/lane reads
+    f16 = known / pick(fetch, "copy_uint4")     # 16 B/lane reads
+    w4 = known / pick(write, "copy_dword")
+    w16 = known / pick(write, "copy_uint4")
+    out = {"n": n, "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; counter units "
+                             "calibrated on copy kernels of known size in the same run (4 B/lane and 16 B/lane)",
+           "bytes_per_fetch_unit": {"dword": f4, "uint4": f16}, "bytes_per_write_unit": {"dword": w4, "uint4": w16},
+           "kernels": {}}
+    for name in fetch:
+        if "onesweep" in name:
+            rd, wr = fetch[name] * f4, write.get(name, 0.0) * w4
+            kind = "key_value" if ", true, " in name.split("onesweep_kernel")[1][:24] else "keys"
+        elif "histogram" in name:
+            rd, wr = fetch[name] * f16, write.get(name, 0.0) * w4
+            kind = "histogram"
+        else:
+            continue
+        out["kernels"][name] = {"kind": kind, "launches": calls[name], "hbm_read_bytes_per_launch": rd,
+                                "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
+        if kind == "keys":
+            out["onesweep_keys_bytes_per_launch"] = rd + wr
+            out["onesweep_keys_algorithmic_bytes_per_launch"] = 8.0 * n
+        if kind == "key_value":
+            out["onesweep_key_value_bytes_per_launch"] = rd + wr
+            out["onesweep_key_value_algorithmic_bytes_per_launch"] = 16.0 * n
+    text = json.dumps(out, indent=1)
+    print(text)
+    if len(sys.argv) > 4:
+        open(sys.argv[4], "w").write(text + "\n")
+
+
+if __name__ == "__main__":
+    main()

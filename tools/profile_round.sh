@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round-end measurement bundle, run ON the GPU box:  gpurun --timeout 1800 -- 'bash tools/profile_round.sh r01'
+# Writes everything under gpurun_out/<tag>/ ; copy the summaries into profiles/ afterwards.
+set -u
+TAG=${1:-r01}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $ROOT
+export TMPDIR=/tmp
+# 1. bench line
+timeout 900 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+# 2. kernel trace + stats of the same command
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kernel_stats -o stats -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err
+# 3. PMC passes (separate runs, counters only + kernel trace)
+(cd tools/probes && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 pmc_calibrate.hip -I$ROOT/include -L$ROOT/vulkan_radix_sort_amd -lvrdx_hip \
+    -Wl,-rpath,$ROOT/vulkan_radix_sort_amd -o /tmp/pmc_calibrate) 2> $OUT/pmc_build.err
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o fetch -- /tmp/pmc_calibrate 25 > $OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- /tmp/pmc_calibrate 25 > $OUT/pmc_write.log 2>&1
+F=$(find $OUT/pmc_fetch -name '*counter_collection.csv' | head -1)
+W=$(find $OUT/pmc_write -name '*counter_collection.csv' | head -1)
+python3 tools/pmc_report.py "$F" "$W" 33554432 $OUT/pmc_traffic.json > $OUT/pmc_report.log 2>&1
+# 4. native sweep over N (the reference's curve: bench/bench.cc:17-20)
+timeout 600 tests/native/vrdx_selftest bench 18 19 20 21 22 23 24 25 > $OUT/native_sweep.txt 2>&1
+ls -R $OUT | head -40

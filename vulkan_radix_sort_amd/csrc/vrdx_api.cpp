@@ -100,6 +100,18 @@ inline uint8_t* BufferAddress(VkBuffer buffer, VkDeviceSize offset) {
   return reinterpret_cast<uint8_t*>(buffer) + offset;
 }
 
+// VRDX_DEBUG=1: report HIP errors of the enqueues on stderr (the entry points themselves return
+// void and validate nothing, like the reference's vrdxCmd*).
+bool DebugEnabled() {
+  static const bool enabled = std::getenv("VRDX_DEBUG") != nullptr;
+  return enabled;
+}
+void DebugCheck(const char* what) {
+  if (!DebugEnabled()) return;
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) std::fprintf(stderr, "vrdx-hip: %s -> %s\n", what, hipGetErrorString(e));
+}
+
 void Stamp(VrdxHipQueryPool* pool, uint32_t slot, hipStream_t stream) {
   if (pool == nullptr || slot >= pool->count) return;
   if (hipEventRecord(pool->events[slot], stream) == hipSuccess) pool->recorded[slot] = 1;
@@ -140,6 +152,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   // Clear count/tickets/failure word, the 4x256 global histogram (reference :382) and status
   // region 0 in one fill; then store the element count where the reference keeps it (:368-379).
   (void)hipMemsetAsync(storage, 0, layout.clearBytes, stream);
+  DebugCheck("hipMemsetAsync(state)");
   if (countPtr != nullptr)
     (void)hipMemcpyAsync(storage + layout.countOffset, countPtr, sizeof(uint32_t),
                          hipMemcpyDeviceToDevice, stream);
@@ -160,6 +173,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     if (grid > cap) grid = cap;
     if (grid == 0) grid = 1;
     vrdx::LaunchHistogram(stream, grid, keys, elementCount, countPtr, globalHistogram);
+    DebugCheck("histogram_kernel");
   }
 
   const uint32_t tiles = vrdx::RoundUp(elementCount, tileKeys);
@@ -190,6 +204,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     args.trace = TraceBuffer(pass, tiles);
 #endif
     vrdx::LaunchOnesweep(stream, configIndex, tiles, keyValue, sorter->atomicRank, args);
+    DebugCheck("onesweep_kernel");
 
     Stamp(pool, query + 2 + 3 * pass + 2, stream);  // "downsweep"
   }
