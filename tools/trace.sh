@@ -11,7 +11,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 d=/tmp/vrdx_trace
 mkdir -p $d "$ROOT/gpurun_out"
 (cd $ROOT/vulkan_radix_sort_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC \
-    -DVRDX_TRACE -x hip vrdx_kernels.hip vrdx_api.cpp -shared -o $d/libvrdx_hip.so) || exit 1
+    -DVRDX_TRACE ${EXTRA_FLAGS:-} -x hip vrdx_kernels.hip vrdx_api.cpp -shared -o $d/libvrdx_hip.so) || exit 1
 LD_LIBRARY_PATH=$d VRDX_TILE_CONFIG=$CONFIG VRDX_TRACE_FILE=$d/trace.bin timeout 120 \
     $ROOT/tests/native/vrdx_selftest trace $LOG2N $KV || exit 1
 python3 $ROOT/tools/trace_report.py $d/trace.bin | tee "$ROOT/gpurun_out/trace_${CONFIG}_${KV}.txt"

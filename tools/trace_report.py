@@ -27,6 +27,11 @@ def main(path):
         # concurrency and start profile
         starts = np.sort(rel[:, 0])
         print("    tile start times (us) at 10% steps:", " ".join(f"{starts[int(q * (tiles - 1))]:.1f}" for q in np.linspace(0, 1, 11)))
+        extra = data[p, :, 7]
+        trips = ((extra >> np.uint64(24 + 16)) & np.uint64(0xFFFF)).astype(np.int64)
+        rows = ((extra >> np.uint64(24)) & np.uint64(0xFFFF)).astype(np.int64)
+        print(f"    look-back trips mean {trips.mean():.2f} p50 {np.median(trips):.0f} p95 {np.percentile(trips, 95):.0f} max {trips.max()};"
+              f" rows walked (digit 0) mean {rows.mean():.1f} p50 {np.median(rows):.0f} p95 {np.percentile(rows, 95):.0f}")
         order = np.argsort(rel[:, 0])
         first = order[: min(600, tiles)]
         lb = dur[:, 4]

@@ -170,6 +170,11 @@ __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t*
 // onesweep: rank + decoupled look-back + scatter, one launch per pass
 // ---------------------------------------------------------------------------------------------
 
+// Measured (tools/trace.sh, profiles/): agent-scope (sc1) status reads cost a CU roughly 13 GB/s,
+// independent of the access width (16-byte row loads were SLOWER: 2.9 us per 4-row trip against
+// 1.5 us per 8-row trip of 4-byte loads), a tile walks ~49 rows = 49 KiB before it meets an
+// inclusive prefix, and that is the 5.6 us it spends here.  Wider windows only add bytes.
+//
 // Decoupled look-back by the WHOLE workgroup.  Thread (g, d) = (tid / 256, tid % 256) inspects
 // kLookBackWindow consecutive predecessor tiles of digit d per trip, group g starting where group
 // g - 1 ends, so one trip covers GROUPS * kLookBackWindow tiles with every status load in flight at
@@ -188,7 +193,7 @@ constexpr int32_t kLookBackDone = INT32_MIN;
 
 template <int THREADS>
 __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t tile, int tid, uint32_t* lds,
-                                             uint32_t* failure) {
+                                             uint32_t* failure, uint32_t* traceTripsRows) {
   constexpr int GROUPS = THREADS / 256;
   constexpr int W = kLookBackWindow;
   int32_t* const pos = reinterpret_cast<int32_t*>(lds);
@@ -199,6 +204,7 @@ __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t ti
 
   uint32_t exclusive = 0;
   uint32_t spins = 0;
+  uint32_t traceTrips = 0, traceRows = 0;  // thread 0 only, reported to tools/trace.sh builds
   bool done = g != 0;  // only group 0 owns the per-digit state
   if (g == 0) pos[d] = (int32_t)tile - 1;
   __syncthreads();
@@ -255,11 +261,14 @@ __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t ti
         }
       }
       pos[d] = done ? kLookBackDone : j - (int32_t)advance;
+      traceRows += advance;
     }
+    ++traceTrips;
     // One barrier + vote: this trip's sum/info are consumed and pos is updated before the next
     // trip touches them.
     if (__syncthreads_and(done ? 1 : 0)) break;
   }
+  if (traceTripsRows != nullptr && tid == 0) *traceTripsRows = (traceTrips << 16) | (traceRows & 0xFFFFu);
   return exclusive;
 }
 
@@ -447,7 +456,9 @@ __global__ __launch_bounds__(THREADS) void onesweep_kernel(OnesweepArgs a) {
   VRDX_STAMP(4);
 
   // ---- decoupled look-back over the preceding tiles, then publish the inclusive prefix --------
-  if (tile != 0 && !(kAblate & 1u)) exclusive = LookBack<THREADS>(a.statusCur, tile, tid, waveHist, a.failure);
+  uint32_t lookBackTrace = 0;
+  if (tile != 0 && !(kAblate & 1u))
+    exclusive = LookBack<THREADS>(a.statusCur, tile, tid, waveHist, a.failure, &lookBackTrace);
   if (tid < 256) {
     if (!lastTile)
       StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid],
@@ -474,7 +485,7 @@ __global__ __launch_bounds__(THREADS) void onesweep_kernel(OnesweepArgs a) {
   if (a.trace != nullptr && tid == 0) {
     uint32_t xcc = 0;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    stamps[7] = ((uint64_t)(xcc & 0xF) << 32) | blockIdx.x;
+    stamps[7] = ((uint64_t)(xcc & 0xF) << 60) | ((uint64_t)lookBackTrace << 24) | (blockIdx.x & 0xFFFFFFu);
     for (int i = 0; i < 8; ++i) a.trace[(size_t)tile * 8 + i] = stamps[i];
   }
 #endif
