@@ -18,7 +18,7 @@ struct TileConfig {
   int keysPerThread;
   uint32_t tileKeys() const { return (uint32_t)threads * (uint32_t)keysPerThread; }
 };
-constexpr int kNumTileConfigs = 5;
+constexpr int kNumTileConfigs = 7;
 extern const TileConfig kTileConfigs[kNumTileConfigs];
 
 struct OnesweepArgs {

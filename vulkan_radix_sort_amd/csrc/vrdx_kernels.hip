@@ -305,44 +305,72 @@ __device__ __forceinline__ void RankBallot(const uint32_t (&key)[KPT], uint32_t 
   }
 }
 
-template <int KPT>
+// PACKED: ranks (< 64 * KPT <= 65536) are written two to a register, out[i / 2] bits 16*(i % 2).
+template <int KPT, bool PACKED>
 __device__ __forceinline__ void RankAtomic(const uint32_t (&key)[KPT], uint32_t shift, uint32_t* myHist,
-                                           int lane, uint32_t (&rank)[KPT]) {
-  bool uniform[KPT];
+                                           int lane, uint32_t (&out)[PACKED ? KPT / 2 : KPT]) {
+  // eight slots at a time: eight atomics in flight, eight wave-uniform flags live (more would
+  // push the 64-bit flag masks out of the scalar register file)
+  constexpr int CHUNK = (KPT % 8 == 0) ? 8 : 4;
+  static_assert(KPT % CHUNK == 0 && CHUNK % 2 == 0, "whole chunks of pairs");
 #pragma unroll
-  for (int i = 0; i < KPT; ++i) {
-    const uint32_t d = (key[i] >> shift) & 0xFFu;
-    const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
-    uniform[i] = __ballot(d != d0) == 0ull;  // wave-uniform
-    uint32_t old = 0;
-    if (!uniform[i] || lane == 0)
-      old = __hip_atomic_fetch_add(&myHist[d], uniform[i] ? 64u : 1u, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-    rank[i] = old;
+  for (int base = 0; base < KPT; base += CHUNK) {
+    bool uniform[CHUNK];
+    uint32_t r[CHUNK];
+#pragma unroll
+    for (int c = 0; c < CHUNK; ++c) {
+      const int i = base + c;
+      const uint32_t d = (key[i] >> shift) & 0xFFu;
+      const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+      uniform[c] = __ballot(d != d0) == 0ull;  // wave-uniform
+      uint32_t old = 0;
+      if (!uniform[c] || lane == 0)
+        old = __hip_atomic_fetch_add(&myHist[d], uniform[c] ? 64u : 1u, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+      r[c] = old;
+    }
+#pragma unroll
+    for (int c = 0; c < CHUNK; ++c) {
+      if (uniform[c]) r[c] = __builtin_amdgcn_readfirstlane(r[c]) + lane;
+      if (PACKED) {
+        if (c % 2 == 1) out[(base + c) / 2] = r[c - 1] | (r[c] << 16);
+      } else {
+        out[base + c] = r[c];
+      }
+    }
   }
-#pragma unroll
-  for (int i = 0; i < KPT; ++i)
-    if (uniform[i]) rank[i] = __builtin_amdgcn_readfirstlane(rank[i]) + lane;
 }
 
+// Key+value tiles replay the permutation for the values through the SAME staging buffer after the
+// keys have left it (like the reference, downsweep.slang:208-224): the LDS footprint equals the
+// keys-only one, so two workgroups fit per CU (keys and values staged together would need 128 KiB
+// at T = 16384: one workgroup per CU and nothing to overlap its waits with).
 template <int THREADS, int KPT, bool KV>
 constexpr size_t OnesweepLdsWords() {
-  // sorted keys (+ sorted values) | per-wave digit counters (later: look-back scratch) |
+  // staging buffer (keys, then values) | per-wave digit counters (later: look-back scratch) |
   // per-digit scatter offsets | scan scratch + ticket
-  return (size_t)THREADS * KPT * (KV ? 2 : 1) + (size_t)(THREADS / 64) * 256 + 256 + 16;
+  return (size_t)THREADS * KPT + (size_t)(THREADS / 64) * 256 + 256 + 16;
+}
+
+// Waves per SIMD the register allocation must leave room for: two workgroups per CU whenever the
+// LDS footprint allows two (every geometry except key+value tiles wider than 16384).
+template <int THREADS, int KPT>
+constexpr int MinWavesPerSimd() {
+  return (OnesweepLdsWords<THREADS, KPT, false>() * 4 * 2 <= 160 * 1024) ? 2 * THREADS / 256 : THREADS / 256;
 }
 
 template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK>
-__global__ __launch_bounds__(THREADS) void onesweep_kernel(OnesweepArgs a) {
+__global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void onesweep_kernel(OnesweepArgs a) {
   constexpr int WAVES = THREADS / 64;
   constexpr uint32_t TILE = THREADS * KPT;
   static_assert(THREADS >= 256 && THREADS % 256 == 0, "one thread per digit, whole look-back groups");
   static_assert(WAVES * 256 >= 256 * (1 + 2 * (THREADS / 256)), "look-back scratch aliases the wave counters");
 
+  static_assert(KPT % 4 == 0, "digits of the value phase are packed four to a register");
+
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  uint32_t* const sortedKeys = smem;                                // TILE: keys regrouped by digit
-  uint32_t* const sortedValues = smem + TILE;                       // TILE (KV only)
-  uint32_t* const waveHist = smem + (KV ? 2 : 1) * TILE;            // WAVES x 256, then look-back scratch
+  uint32_t* const sorted = smem;                                    // TILE: keys (then values) regrouped by digit
+  uint32_t* const waveHist = smem + TILE;                           // WAVES x 256, then look-back scratch
   uint32_t* const tileOffset = waveHist + WAVES * 256;              // 256: global base - tile-local base
   uint32_t* const scanScratch = tileOffset + 256;                   // 8
   uint32_t* const misc = scanScratch + 8;                           // [0] ticket
@@ -376,40 +404,32 @@ __global__ __launch_bounds__(THREADS) void onesweep_kernel(OnesweepArgs a) {
   }
 
   // ---- load: wave-striped, so that (slot, lane) order == memory order inside a wave ----------
+  // (the values are fetched once the keys have been staged)
   uint32_t key[KPT];
-  uint32_t val[KV ? KPT : 1];
-  {
-    const uint32_t base = tileStart + wave * (KPT * 64) + lane;
-    if (valid == TILE) {
+  const uint32_t loadBase = tileStart + wave * (KPT * 64) + lane;
+  if (valid == TILE) {
 #pragma unroll
-      for (int i = 0; i < KPT; ++i) key[i] = a.keysIn[base + i * 64];
-      if (KV) {
+    for (int i = 0; i < KPT; ++i) key[i] = a.keysIn[loadBase + i * 64];
+  } else {
+    // Ragged last tile: pad with 0xFFFFFFFF like the reference (downsweep.slang:81).  Pads sit
+    // at the highest memory positions of the tile and have digit 255 in every pass, so the
+    // stable ranking puts them at tile-local positions >= valid, where nothing is written.
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) val[i] = a.valuesIn[base + i * 64];
-      }
-    } else {
-      // Ragged last tile: pad with 0xFFFFFFFF like the reference (downsweep.slang:81).  Pads sit
-      // at the highest memory positions of the tile and have digit 255 in every pass, so the
-      // stable ranking puts them at tile-local positions >= valid, where nothing is written.
-#pragma unroll
-      for (int i = 0; i < KPT; ++i) {
-        const uint32_t idx = base + i * 64;
-        key[i] = idx < n ? a.keysIn[idx] : 0xFFFFFFFFu;
-      }
-      if (KV) {
-#pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-          const uint32_t idx = base + i * 64;
-          val[i] = idx < n ? a.valuesIn[idx] : 0u;
-        }
-      }
+    for (int i = 0; i < KPT; ++i) {
+      const uint32_t idx = loadBase + i * 64;
+      key[i] = idx < n ? a.keysIn[idx] : 0xFFFFFFFFu;
     }
   }
 
   // ---- rank inside the wave (memory order) ---------------------------------------------------
-  uint32_t rank[KPT];
-  if (ATOMIC_RANK)
-    RankAtomic<KPT>(key, a.shift, waveHist + wave * 256, lane, rank);
+  // key+value: ranks / positions live until the values are staged, so they are kept packed two to
+  // a register (< TILE <= 65536) -- two workgroups per CU must fit the register file with no spill
+  // at all (measured: 120 bytes of scratch per lane made a pass 30x slower).
+  constexpr bool PACKED = KV && ATOMIC_RANK;
+  static_assert(!KV || TILE <= 65536, "packed 16-bit positions");
+  uint32_t rank[PACKED ? KPT / 2 : KPT];
+  if constexpr (ATOMIC_RANK)
+    RankAtomic<KPT, PACKED>(key, a.shift, waveHist + wave * 256, lane, rank);
   else
     RankBallot<KPT>(key, a.shift, waveHist + wave * 256, lane, rank);
   __syncthreads();
@@ -443,17 +463,35 @@ __global__ __launch_bounds__(THREADS) void onesweep_kernel(OnesweepArgs a) {
   __syncthreads();
   VRDX_STAMP(3);
 
-  // ---- regroup keys (and values) by digit in LDS; registers are free afterwards --------------
+  // ---- regroup the keys by digit in LDS; key+value keeps the positions for the values ----------
+  uint32_t packedPos[KV ? KPT / 2 : 1];
 #pragma unroll
   for (int i = 0; i < KPT; ++i) {
     const uint32_t d = (key[i] >> a.shift) & 0xFFu;
-    uint32_t p = rank[i] + waveHist[wave * 256 + d];  // tile-local sorted position
+    const uint32_t r = PACKED ? ((rank[i / 2] >> (16 * (i % 2))) & 0xFFFFu) : rank[PACKED ? 0 : i];
+    uint32_t p = r + waveHist[wave * 256 + d];  // tile-local sorted position
     if (kAblate & (2u | 16u)) p = (p + i * 64 + wave * KPT * 64) % TILE;
-    sortedKeys[p] = key[i];
-    if (KV) sortedValues[p] = val[i];
+    sorted[p] = key[i];
+    if (KV) packedPos[i / 2] = (i % 2 == 0) ? p : (packedPos[i / 2] | (p << 16));
   }
   __syncthreads();  // waveHist is dead from here on: the look-back reuses it as scratch
   VRDX_STAMP(4);
+
+  // The keys' registers are free now: fetch the values; the look-back covers their latency.
+  // (after the barrier, so that they cannot be hoisted into the staging loop next to the keys)
+  uint32_t val[KV ? KPT : 1];
+  if (KV) {
+    if (valid == TILE) {
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) val[i] = a.valuesIn[loadBase + i * 64];
+    } else {
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        const uint32_t idx = loadBase + i * 64;
+        val[i] = idx < n ? a.valuesIn[idx] : 0u;  // downsweep.slang:85
+      }
+    }
+  }
 
   // ---- decoupled look-back over the preceding tiles, then publish the inclusive prefix --------
   uint32_t lookBackTrace = 0;
@@ -469,15 +507,36 @@ __global__ __launch_bounds__(THREADS) void onesweep_kernel(OnesweepArgs a) {
   VRDX_STAMP(5);
 
   // ---- scatter: consecutive lanes -> consecutive addresses inside each digit run --------------
+  uint32_t digits[KV ? KPT / 4 : 1];  // key+value: digit of every scatter slot, four to a register
 #pragma unroll
   for (int j = 0; j < KPT; ++j) {
     const uint32_t p = tid + j * THREADS;
+    uint32_t d = 0;
     if (p < valid) {
-      const uint32_t k = sortedKeys[p];
-      const uint32_t d = (k >> a.shift) & 0xFFu;
+      const uint32_t k = sorted[p];
+      d = (k >> a.shift) & 0xFFu;
       const uint32_t o = (kAblate & 4u) ? tileStart + p : tileOffset[d] + p;
       a.keysOut[o] = k;
-      if (KV) a.valuesOut[o] = sortedValues[p];
+    }
+    if (KV) {
+      digits[j / 4] = (j % 4 == 0) ? d : (digits[j / 4] | (d << (8 * (j % 4))));
+      // values and positions are live here: keep the scheduler from batching all KPT LDS reads
+      if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (KV) {
+    __syncthreads();  // every key has left the staging buffer
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) sorted[(packedPos[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const uint32_t p = tid + j * THREADS;
+      if (p < valid) {
+        const uint32_t d = (digits[j / 4] >> (8 * (j % 4))) & 0xFFu;
+        const uint32_t o = (kAblate & 4u) ? tileStart + p : tileOffset[d] + p;
+        a.valuesOut[o] = sorted[p];
+      }
     }
   }
 #ifdef VRDX_TRACE
@@ -515,7 +574,7 @@ __global__ __launch_bounds__(1024) void lds_order_check_kernel(uint32_t* mismatc
       const uint32_t mask = mode == 0 ? 0u : mode == 1 ? 1u : mode == 2 ? 3u : mode == 3 ? 15u : mode == 4 ? 0x21u : 255u;
       key[i] = x & mask;
     }
-    RankAtomic<8>(key, 0, histA, lane, ra);
+    RankAtomic<8, false>(key, 0, histA, lane, ra);
     RankBallot<8>(key, 0, histB, lane, rb);
 #pragma unroll
     for (int i = 0; i < 8; ++i) bad += ra[i] != rb[i];
@@ -567,7 +626,7 @@ static void LaunchConfig(hipStream_t stream, uint32_t grid, bool keyValue, bool 
 }
 
 const TileConfig kTileConfigs[kNumTileConfigs] = {
-    {512, 16}, {1024, 16}, {512, 32}, {1024, 8}, {256, 32},
+    {512, 16}, {1024, 16}, {512, 32}, {1024, 8}, {256, 32}, {512, 24}, {512, 28},
 };
 
 hipError_t PrepareKernels(int configIndex) {
@@ -577,6 +636,8 @@ hipError_t PrepareKernels(int configIndex) {
     case 2: return PrepareConfig<512, 32>();
     case 3: return PrepareConfig<1024, 8>();
     case 4: return PrepareConfig<256, 32>();
+    case 5: return PrepareConfig<512, 24>();
+    case 6: return PrepareConfig<512, 28>();
     default: return hipErrorInvalidValue;
   }
 }
@@ -610,6 +671,8 @@ void LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool key
     case 2: LaunchConfig<512, 32>(stream, grid, keyValue, atomicRank, args); break;
     case 3: LaunchConfig<1024, 8>(stream, grid, keyValue, atomicRank, args); break;
     case 4: LaunchConfig<256, 32>(stream, grid, keyValue, atomicRank, args); break;
+    case 5: LaunchConfig<512, 24>(stream, grid, keyValue, atomicRank, args); break;
+    case 6: LaunchConfig<512, 28>(stream, grid, keyValue, atomicRank, args); break;
     default: break;
   }
 }
