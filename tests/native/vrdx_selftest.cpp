@@ -337,8 +337,8 @@ uint64_t Median(std::vector<uint64_t> v) {
 }
 
 void Bench(Harness& h, const std::vector<int>& logs) {
-  std::printf("%-10s %-6s %10s %10s %12s %10s %8s   stage ms (hist | scatter x4)\n", "n", "sort", "gpu_ms", "wall_ms",
-              "GItems/s", "GB/s", "%8TB/s");
+  std::printf("%-10s %-6s %10s %10s %12s %10s %8s   [with 15 timestamps] stage ms (hist | scatter x4)\n", "n", "sort",
+              "gpu_ms", "wall_ms", "GItems/s", "GB/s", "%8TB/s");
   for (int lg : logs) {
     const uint32_t n = 1u << lg;
     for (int kv = 0; kv < 2; ++kv) {
@@ -372,16 +372,117 @@ void Bench(Harness& h, const std::vector<int>& logs) {
         stage[0].push_back(ts[2] - ts[1]);
         for (int p = 0; p < 4; ++p) stage[1 + p].push_back(ts[4 + 3 * p] - ts[3 + 3 * p]);
       }
-      const double ms = Median(gpu) / 1e6;
+      // the same sort recorded WITHOUT a query pool (no per-stage events), bracketed by two events
+      std::vector<uint64_t> bare;
+      {
+        hipEvent_t e0, e1;
+        HIP_OK(hipEventCreate(&e0));
+        HIP_OK(hipEventCreate(&e1));
+        for (int runIdx = 0; runIdx < 11; ++runIdx) {
+          std::vector<uint32_t> v;
+          auto k = Mt(n, runIdx + 1, 32, &v);
+          HIP_OK(hipMemcpy(h.dKeys, k.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+          HIP_OK(hipMemcpy(h.dKeys + inout, v.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+          HIP_OK(hipDeviceSynchronize());
+          HIP_OK(hipEventRecord(e0, h.stream));
+          if (kv)
+            vrdxCmdSortKeyValue((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dKeys, inout,
+                                (VkBuffer)h.dStorage, 0, VK_NULL_HANDLE, 0);
+          else
+            vrdxCmdSort((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dStorage, 0,
+                        VK_NULL_HANDLE, 0);
+          HIP_OK(hipEventRecord(e1, h.stream));
+          HIP_OK(hipStreamSynchronize(h.stream));
+          float msf = 0;
+          HIP_OK(hipEventElapsedTime(&msf, e0, e1));
+          if (runIdx > 0) bare.push_back((uint64_t)(msf * 1e6));
+        }
+        HIP_OK(hipEventDestroy(e0));
+        HIP_OK(hipEventDestroy(e1));
+      }
+      const double ms = Median(bare) / 1e6;       // headline: no per-stage events inside the sort
+      const double msStamped = Median(gpu) / 1e6; // with the 15-slot timestamp contract active
       const double bytes = (kv ? 68.0 : 36.0) * n;  // algorithmic bytes, SURVEY.md section 8(d)
       const double gbps = bytes / (ms * 1e-3) / 1e9;
-      std::printf("%-10u %-6s %10.4f %10.4f %12.3f %10.1f %7.1f%%   %.4f | %.4f %.4f %.4f %.4f\n", n,
-                  kv ? "kv" : "keys", ms, Median(wall) / 1e6, n / (ms * 1e-3) / 1e9, gbps, 100.0 * gbps / 8000.0,
+      std::printf("%-10u %-6s %10.4f %10.4f %12.3f %10.1f %7.1f%%   [stamped %.4f] %.4f | %.4f %.4f %.4f %.4f\n", n,
+                  kv ? "kv" : "keys", ms, Median(wall) / 1e6, n / (ms * 1e-3) / 1e9, gbps, 100.0 * gbps / 8000.0, msStamped,
                   Median(stage[0]) / 1e6, Median(stage[1]) / 1e6, Median(stage[2]) / 1e6, Median(stage[3]) / 1e6,
                   Median(stage[4]) / 1e6);
       std::fflush(stdout);
     }
   }
+}
+
+
+// BASELINE.json configs[3]: N = 2^25 adversarial keys (all-equal, all-0xFFFFFFFF, descending,
+// few-distinct) against uniform random; values = iota, parity checked with the oracle for the
+// stable permutation, then timed (median of 5, data re-uploaded before every run).
+int Adversarial(Harness& h, int lg) {
+  const uint32_t n = 1u << lg;
+  const uint32_t inout = Align16(n * 4u);
+  VrdxSorterStorageRequirements req;
+  vrdxGetSorterKeyValueStorageRequirements(h.sorter, n, &req);
+  h.reserve((size_t)2 * inout + 16, (size_t)req.size);
+  std::vector<uint32_t> iota(n), k(n);
+  for (uint32_t i = 0; i < n; ++i) iota[i] = i;
+  std::mt19937 g(4);
+  const char* names[] = {"uniform", "all-equal", "all-0xFFFFFFFF", "descending", "ascending", "few-distinct(4)"};
+  double base[2] = {0, 0};
+  int failures = 0;
+  std::printf("%-18s %-5s %10s %12s %10s %s\n", "keys", "sort", "gpu_ms", "GItems/s", "slowdown", "parity");
+  for (int pattern = 0; pattern < 6; ++pattern) {
+    const uint32_t four[4] = {3u, 0xFFFFFFFFu, 0x00010000u, 0x7F000000u};
+    for (uint32_t i = 0; i < n; ++i) {
+      switch (pattern) {
+        case 0: k[i] = g(); break;
+        case 1: k[i] = 0x12345678u; break;
+        case 2: k[i] = 0xFFFFFFFFu; break;
+        case 3: k[i] = n - 1 - i; break;
+        case 4: k[i] = i; break;
+        default: k[i] = four[g() & 3]; break;
+      }
+    }
+    std::vector<uint32_t> ek = k, ev = iota;
+    vrdx_oracle_sort(ek.data(), ev.data(), n, nullptr);
+    for (int kv = 0; kv < 2; ++kv) {
+      std::vector<uint64_t> times;
+      bool ok = true;
+      double stageHist = 0, stagePass[4] = {0, 0, 0, 0};
+      for (int run = 0; run < 6; ++run) {
+        HIP_OK(hipMemcpy(h.dKeys, k.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(h.dKeys + inout, iota.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipDeviceSynchronize());
+        if (kv)
+          vrdxCmdSortKeyValue((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dKeys, inout,
+                              (VkBuffer)h.dStorage, 0, h.pool, 0);
+        else
+          vrdxCmdSort((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dStorage, 0, h.pool, 0);
+        HIP_OK(hipStreamSynchronize(h.stream));
+        uint64_t ts[15];
+        if (vrdxHipGetQueryPoolResults(h.pool, 0, 15, ts) != VK_SUCCESS) return 3;
+        if (run > 0) times.push_back(ts[14]);
+        if (run == 5) {
+          stageHist = (ts[2] - ts[1]) / 1e6;
+          for (int p = 0; p < 4; ++p) stagePass[p] = (ts[4 + 3 * p] - ts[3 + 3 * p]) / 1e6;
+        }
+        if (run == 0) {
+          std::vector<uint32_t> gk(n), gv(n);
+          HIP_OK(hipMemcpy(gk.data(), h.dKeys, (size_t)n * 4, hipMemcpyDeviceToHost));
+          HIP_OK(hipMemcpy(gv.data(), h.dKeys + inout, (size_t)n * 4, hipMemcpyDeviceToHost));
+          ok = gk == ek && (!kv || gv == ev);
+          if (vrdxHipReadStatus((VkCommandBuffer)h.stream, (VkBuffer)h.dStorage, 0) != 0) ok = false;
+        }
+      }
+      const double ms = Median(times) / 1e6;
+      if (pattern == 0) base[kv] = ms;
+      if (!ok) ++failures;
+      std::printf("%-18s %-5s %10.4f %12.3f %9.2fx %-8s hist %.4f | passes %.4f %.4f %.4f %.4f\n", names[pattern],
+                  kv ? "kv" : "keys", ms, n / (ms * 1e-3) / 1e9, ms / base[kv], ok ? "ok" : "MISMATCH", stageHist,
+                  stagePass[0], stagePass[1], stagePass[2], stagePass[3]);
+      std::fflush(stdout);
+    }
+  }
+  return failures;
 }
 
 }  // namespace
@@ -414,6 +515,7 @@ int main(int argc, char** argv) {
     vrdxDestroySorter(h.sorter);
     return 0;
   }
+  if (what == "adversarial") return Adversarial(h, argc > 2 ? std::atoi(argv[2]) : 25) ? 1 : 0;
   if (what == "bench") {
     std::vector<int> logs;
     for (int i = 2; i < argc; ++i) logs.push_back(std::atoi(argv[i]));
@@ -421,6 +523,6 @@ int main(int argc, char** argv) {
     Bench(h, logs);
     return 0;
   }
-  std::fprintf(stderr, "usage: %s parity|quick|bench [log2n...]\n", argv[0]);
+  std::fprintf(stderr, "usage: %s parity|quick|bench [log2n...]|adversarial [log2n]|trace\n", argv[0]);
   return 64;
 }

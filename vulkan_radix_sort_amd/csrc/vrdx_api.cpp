@@ -22,8 +22,7 @@
 struct VrdxSorter_T {
   int device = 0;
   int computeUnits = 0;
-  int configKeys = 0;      // tile geometry of the keys-only kernels
-  int configKeyValue = 0;  // tile geometry of the key+value kernels
+  // (tile geometry is chosen per sort from the element count, see ConfigIndex)
   bool atomicRank = false;  // LDS returning atomics proven lane-ordered on this device
   // reference: VrdxSorter_T::minStorageBufferOffsetAlignment (src/vk_radix_sort.h.in:134)
   uint32_t minStorageBufferOffsetAlignment = VRDX_STORAGE_ALIGN;
@@ -43,58 +42,32 @@ int DeviceOrdinalFromHandle(const void* handle, int* ordinal) {
   return 0;
 }
 
-// Measured on MI355X at N = 2^25 (profiles/): keys-only is fastest with 16384-key tiles of 512
-// threads (2 workgroups per CU), key+value with 16384-key tiles of 1024 threads.
-constexpr int kDefaultConfigKeys = 2;      // 512 x 32
-constexpr int kDefaultConfigKeyValue = 1;  // 1024 x 16
-
-int ConfigIndex(bool keyValue) {
-  const char* env = std::getenv("VRDX_TILE_CONFIG");  // e.g. "512x16": overrides both; tuning/testing knob
-  if (env != nullptr) {
+// Tile geometry by problem size, measured on MI355X (profiles/r01_native_sweep_n.txt): small sorts
+// want many small tiles (parallelism across 256 CUs), large sorts want 16384-key tiles of 512
+// threads (fewer look-back rows per key, two workgroups per CU).
+//   index into vrdx::kTileConfigs: 0 = 512x16, 1 = 1024x16, 2 = 512x32, 3 = 1024x8, ...
+int ForcedConfigIndex() {
+  static const int forced = [] {
+    const char* env = std::getenv("VRDX_TILE_CONFIG");  // e.g. "512x16": one geometry for everything (tuning/testing)
+    if (env == nullptr) return -1;
     for (int i = 0; i < vrdx::kNumTileConfigs; ++i) {
       char name[32];
-      std::snprintf(name, sizeof(name), "%dx%d", vrdx::kTileConfigs[i].threads,
-                    vrdx::kTileConfigs[i].keysPerThread);
+      std::snprintf(name, sizeof(name), "%dx%d", vrdx::kTileConfigs[i].threads, vrdx::kTileConfigs[i].keysPerThread);
       if (std::strcmp(env, name) == 0) return i;
     }
-    std::fprintf(stderr, "vrdx-hip: unknown VRDX_TILE_CONFIG '%s', using default\n", env);
-  }
-  return keyValue ? kDefaultConfigKeyValue : kDefaultConfigKeys;
+    std::fprintf(stderr, "vrdx-hip: unknown VRDX_TILE_CONFIG '%s', using the defaults\n", env);
+    return -1;
+  }();
+  return forced;
 }
 
-#ifdef VRDX_TRACE
-// tools/trace.sh only: one device buffer of 8 stamps per (pass, tile), dumped to $VRDX_TRACE_FILE
-// by vrdxDestroySorter.  Holds the LAST sort recorded before the dump.
-unsigned long long* g_trace = nullptr;
-uint32_t g_traceTiles = 0;
-constexpr uint32_t kTraceMaxTiles = 1u << 16;
-unsigned long long* TraceBuffer(uint32_t pass, uint32_t tiles) {
-  if (g_trace == nullptr) {
-    if (hipMalloc(reinterpret_cast<void**>(&g_trace), 4ull * kTraceMaxTiles * 8 * sizeof(unsigned long long)) !=
-        hipSuccess)
-      return nullptr;
-  }
-  if (tiles > kTraceMaxTiles) return nullptr;
-  g_traceTiles = tiles;
-  return g_trace + (size_t)pass * kTraceMaxTiles * 8;
+int ConfigIndex(bool keyValue, uint32_t elementCount) {
+  const int forced = ForcedConfigIndex();
+  if (forced >= 0) return forced;
+  if (elementCount <= (1u << 19)) return 3;                          // 1024 x 8   (T = 8192)
+  if (elementCount <= (keyValue ? 6u : 12u) * (1u << 20)) return 1;  // 1024 x 16  (T = 16384, 16 waves)
+  return 2;                                                          // 512 x 32   (T = 16384, 2 workgroups / CU)
 }
-void DumpTrace() {
-  const char* path = std::getenv("VRDX_TRACE_FILE");
-  if (g_trace == nullptr || path == nullptr) return;
-  (void)hipDeviceSynchronize();
-  const size_t words = 4ull * kTraceMaxTiles * 8;
-  unsigned long long* host = new unsigned long long[words];
-  if (hipMemcpy(host, g_trace, words * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
-    if (FILE* f = std::fopen(path, "wb")) {
-      std::fwrite(&g_traceTiles, sizeof(g_traceTiles), 1, f);
-      for (uint32_t pass = 0; pass < 4; ++pass)
-        std::fwrite(host + (size_t)pass * kTraceMaxTiles * 8, sizeof(unsigned long long), (size_t)g_traceTiles * 8, f);
-      std::fclose(f);
-    }
-  }
-  delete[] host;
-}
-#endif
 
 inline uint8_t* BufferAddress(VkBuffer buffer, VkDeviceSize offset) {
   return reinterpret_cast<uint8_t*>(buffer) + offset;
@@ -128,7 +101,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   const bool keyValue = valuesBuffer != nullptr;
   if (elementCount > VRDX_MAX_ELEMENTS) elementCount = VRDX_MAX_ELEMENTS;
 
-  const int configIndex = keyValue ? sorter->configKeyValue : sorter->configKeys;
+  const int configIndex = ConfigIndex(keyValue, elementCount);
   const uint32_t tileKeys = vrdx::kTileConfigs[configIndex].tileKeys();
   const vrdx::StorageLayout layout =
       vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, tileKeys);
@@ -237,14 +210,11 @@ VkResult vrdxCreateSorter(const VrdxSorterCreateInfo* pCreateInfo, VrdxSorter* p
   if (sorter == nullptr) return VK_ERROR_OUT_OF_HOST_MEMORY;
   sorter->device = ordinal;
   sorter->computeUnits = prop.multiProcessorCount;
-  sorter->configKeys = ConfigIndex(false);
-  sorter->configKeyValue = ConfigIndex(true);
 
   int previous = 0;
   (void)hipGetDevice(&previous);
   hipError_t e = hipSetDevice(ordinal);
-  if (e == hipSuccess) e = vrdx::PrepareKernels(sorter->configKeys);
-  if (e == hipSuccess) e = vrdx::PrepareKernels(sorter->configKeyValue);
+  for (int i = 0; i < vrdx::kNumTileConfigs && e == hipSuccess; ++i) e = vrdx::PrepareKernels(i);
   if (e == hipSuccess) {
     // Ranking mode: the single-atomic form needs a hardware property the ISA manual does not
     // promise, so it is verified here, once, on this very device; VRDX_RANK=ballot|atomic|auto.
@@ -279,16 +249,18 @@ void vrdxDestroySorter(VrdxSorter sorter) {
 
 void vrdxGetSorterStorageRequirements(VrdxSorter sorter, uint32_t maxElementCount,
                                       VrdxSorterStorageRequirements* requirements) {
-  const vrdx::StorageLayout layout = vrdx::MakeLayout(maxElementCount, sorter->minStorageBufferOffsetAlignment,
-                                                      vrdx::kTileConfigs[sorter->configKeys].tileKeys());
+  const vrdx::StorageLayout layout =
+      vrdx::MakeLayout(maxElementCount, sorter->minStorageBufferOffsetAlignment,
+                       vrdx::kTileConfigs[ConfigIndex(false, maxElementCount)].tileKeys());
   requirements->size = layout.keysOnlySize;
   requirements->usage = VK_BUFFER_USAGE_STORAGE_BUFFER_BIT | VK_BUFFER_USAGE_TRANSFER_DST_BIT;
 }
 
 void vrdxGetSorterKeyValueStorageRequirements(VrdxSorter sorter, uint32_t maxElementCount,
                                               VrdxSorterStorageRequirements* requirements) {
-  const vrdx::StorageLayout layout = vrdx::MakeLayout(maxElementCount, sorter->minStorageBufferOffsetAlignment,
-                                                      vrdx::kTileConfigs[sorter->configKeyValue].tileKeys());
+  const vrdx::StorageLayout layout =
+      vrdx::MakeLayout(maxElementCount, sorter->minStorageBufferOffsetAlignment,
+                       vrdx::kTileConfigs[ConfigIndex(true, maxElementCount)].tileKeys());
   requirements->size = layout.keyValueSize;
   requirements->usage = VK_BUFFER_USAGE_STORAGE_BUFFER_BIT | VK_BUFFER_USAGE_TRANSFER_DST_BIT;
 }
@@ -393,10 +365,11 @@ uint32_t vrdxHipReadStatus(VkCommandBuffer commandBuffer, VkBuffer storageBuffer
 
 const char* vrdxHipVersionString(void) {
   static char text[128];
-  const vrdx::TileConfig& k = vrdx::kTileConfigs[ConfigIndex(false)];
-  const vrdx::TileConfig& kv = vrdx::kTileConfigs[ConfigIndex(true)];
-  std::snprintf(text, sizeof(text), "vrdx-hip %d.%d.%d gfx950 tile keys=%dx%d key-value=%dx%d", VRDX_VERSION_MAJOR,
-                VRDX_VERSION_MINOR, VRDX_VERSION_PATCH, k.threads, k.keysPerThread, kv.threads, kv.keysPerThread);
+  const vrdx::TileConfig& k = vrdx::kTileConfigs[ConfigIndex(false, 1u << 25)];
+  const vrdx::TileConfig& kv = vrdx::kTileConfigs[ConfigIndex(true, 1u << 25)];
+  std::snprintf(text, sizeof(text), "vrdx-hip %d.%d.%d gfx950 tiles at 2^25: keys=%dx%d key-value=%dx%d%s",
+                VRDX_VERSION_MAJOR, VRDX_VERSION_MINOR, VRDX_VERSION_PATCH, k.threads, k.keysPerThread, kv.threads,
+                kv.keysPerThread, ForcedConfigIndex() >= 0 ? " (forced)" : " (size-adaptive)");
   return text;
 }
 
