@@ -345,6 +345,28 @@ def test_full_size_adversarial(torch_mod, sorter, oracle):
         assert int(gp.astype(np.uint64).sum()) == n * (n - 1) // 2, name
 
 
+def test_large_ragged_2pow28_properties(torch_mod, sorter):
+    """N = 2^28 + 12345 keys-only (1 GiB of keys, ragged last tile): index arithmetic far above the
+    benchmark size.  Size-independent properties only: sortedness and a multiset checksum."""
+    torch = torch_mod
+    n = (1 << 28) + 12345
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    keys = torch.randint(-(1 << 31), 1 << 31, (n,), generator=g, device="cuda", dtype=torch.int64).to(torch.int32)
+    total_before = int((keys.to(torch.int64) & 0xFFFFFFFF).sum().item())
+    xor_before = int(torch.bitwise_xor(keys[: n // 2 * 2].view(-1, 2)[:, 0], keys[: n // 2 * 2].view(-1, 2)[:, 1]).sum().item())
+    req = sorter.storage_requirements(n)
+    storage = torch.empty(req.size, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    sorter.cmd_sort(stream, n, keys.data_ptr(), 0, storage.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert sorter.read_status(stream, storage.data_ptr(), 0) == 0
+    u = keys.to(torch.int64) & 0xFFFFFFFF
+    assert bool((u[1:] >= u[:-1]).all())
+    assert int(u.sum().item()) == total_before
+    del u, xor_before
+
+
 def test_native_selftest_binary(torch_mod):
     """The same battery from plain C++ (no torch in the process): tests/native/vrdx_selftest."""
     exe = os.path.join(ROOT, "tests", "native", "vrdx_selftest")
