@@ -1,0 +1,62 @@
+// Backends of the bench driver.  Mirrors the reference's BenchmarkBase / BenchmarkFactory /
+// DataGenerator interfaces (/root/reference/bench/benchmark_base.h:9-29, benchmark_factory.h,
+// data_generator.h:8-24) so that bench.cc reads like the reference's driver.
+#ifndef VRDX_BENCH_BACKENDS_H
+#define VRDX_BENCH_BACKENDS_H
+
+#include <cstdint>
+#include <memory>
+#include <random>
+#include <string>
+#include <vector>
+
+class BenchmarkBase {
+ public:
+  struct Results {
+    std::vector<uint32_t> keys;
+    std::vector<uint32_t> values;
+    uint64_t total_time = 0;    // ns, device time of the whole sort
+    uint64_t cpu_time = 0;      // ns, wall clock submit -> completion
+    uint64_t upsweep_ns = 0;    // ns, summed over the 4 passes (ours: the fused histogram)
+    uint64_t spine_ns = 0;      // ns (ours: 0, the scan is the look-back inside downsweep)
+    uint64_t downsweep_ns = 0;  // ns, summed over the 4 passes
+  };
+  virtual ~BenchmarkBase() = default;
+  virtual std::string LibraryVersion() const { return ""; }
+  virtual Results Sort(const std::vector<uint32_t>& keys) = 0;
+  virtual Results SortKeyValue(const std::vector<uint32_t>& keys, const std::vector<uint32_t>& values) = 0;
+};
+
+struct SortData {
+  std::vector<uint32_t> keys;
+  std::vector<uint32_t> values;
+};
+
+// N keys first, then N values, raw mt19937 outputs (what libstdc++'s uniform_int_distribution
+// over the full uint32 range yields; bench/data_generator.cc:12-26).
+class DataGenerator {
+ public:
+  DataGenerator() : gen_(std::random_device{}()) {}
+  explicit DataGenerator(int seed) : gen_(seed) {}
+  SortData Generate(uint32_t size, uint32_t bits = 32) {
+    SortData d;
+    d.keys.resize(size);
+    d.values.resize(size);
+    for (auto& k : d.keys) {
+      const uint32_t x = gen_();
+      k = bits >= 32 ? x : (bits == 0 ? 0u : x >> (32 - bits));
+    }
+    for (auto& v : d.values) v = gen_();
+    return d;
+  }
+
+ private:
+  std::mt19937 gen_;
+};
+
+// "hip" (libvrdx_hip.so through the C-ABI), "cpu" (std::sort / std::stable_sort), and "rocprim"
+// when the driver was built with the comparator (bench/rocprim_backend.hip).
+std::unique_ptr<BenchmarkBase> CreateBenchmark(const std::string& type);
+std::unique_ptr<BenchmarkBase> CreateRocprimBenchmark();  // nullptr when not compiled in
+
+#endif  // VRDX_BENCH_BACKENDS_H

@@ -85,3 +85,20 @@ def test_header_compiles_as_c_and_cpp(tmp_path, compiler, lang):
     subprocess.run([compiler, "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
                    check=True)
     assert subprocess.run([str(exe)]).returncode == 0
+
+
+def test_bench_driver_cpu_backend_and_csv_format(tmp_path):
+    """bench/bench (the reference's bench/bench.cc protocol): cpu backend runs without a GPU and the
+    CSV keeps the reference's seven columns (tools/plot.py reads them) plus the two roofline ones."""
+    exe = os.path.join(ROOT, "bench", "bench")
+    if not os.path.exists(exe):
+        pytest.skip("bench/bench not built (needs hipcc for the rocPRIM comparator)")
+    out = tmp_path / "r.csv"
+    subprocess.run([exe, "cpu", "--points", "3", "--min-log2n", "10", "--max-log2n", "13", "-o", str(out)],
+                   check=True, stdout=subprocess.DEVNULL)
+    lines = [l for l in out.read_text().splitlines() if not l.startswith("#")]
+    assert lines[0] == "backend,n,sort,gpu_ms,cpu_ms,gpu_gitems_s,cpu_gitems_s,achieved_GBps,hbm_fraction"
+    rows = [l.split(",") for l in lines[1:]]
+    assert [r[1] for r in rows] == ["1024", "1024", "4608", "4608", "8192", "8192"]
+    assert [r[2] for r in rows] == ["keys", "kv"] * 3
+    assert all(r[0] == "cpu" and float(r[3]) > 0 for r in rows)
