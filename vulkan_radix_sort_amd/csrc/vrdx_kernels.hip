@@ -383,12 +383,6 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
 #endif
   VRDX_STAMP(0);
 
-#ifdef VRDX_STAGGER
-  // experiment: de-phase the first wave of workgroups so that loads of one half overlap stores of the other
-  if (blockIdx.x < 512u && ((blockIdx.x >> VRDX_STAGGER_BIT) & 1u)) {
-    for (int s = 0; s < VRDX_STAGGER; ++s) __builtin_amdgcn_s_sleep(127);
-  }
-#endif
   if (tid == 0) misc[0] = (kAblate & 8u) ? blockIdx.x : atomicAdd(a.ticketCur, 1u);
   for (int i = tid; i < WAVES * 256; i += THREADS) waveHist[i] = 0;
   __syncthreads();
