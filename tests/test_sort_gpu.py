@@ -377,7 +377,7 @@ def test_native_selftest_binary(torch_mod):
     assert "0 failures" in r.stdout
 
 
-@pytest.mark.parametrize("config", ["1024x16", "512x32", "1024x8", "256x32"])
+@pytest.mark.parametrize("config", ["1024x16", "512x32", "1024x8", "512x16", "512x24"])
 def test_other_tile_configs(torch_mod, oracle, config):
     """Every compiled tile geometry is parity-clean, not only the default one."""
     exe = os.path.join(ROOT, "tests", "native", "vrdx_selftest")

@@ -69,6 +69,40 @@ int ConfigIndex(bool keyValue, uint32_t elementCount) {
   return 2;                                                          // 512 x 32   (T = 16384, 2 workgroups / CU)
 }
 
+#ifdef VRDX_TRACE
+// tools/trace.sh only: one device buffer of 8 stamps per (pass, tile), dumped to $VRDX_TRACE_FILE
+// by vrdxDestroySorter.  Holds the LAST sort recorded before the dump.
+unsigned long long* g_trace = nullptr;
+uint32_t g_traceTiles = 0;
+constexpr uint32_t kTraceMaxTiles = 1u << 16;
+unsigned long long* TraceBuffer(uint32_t pass, uint32_t tiles) {
+  if (g_trace == nullptr) {
+    if (hipMalloc(reinterpret_cast<void**>(&g_trace), 4ull * kTraceMaxTiles * 8 * sizeof(unsigned long long)) !=
+        hipSuccess)
+      return nullptr;
+  }
+  if (tiles > kTraceMaxTiles) return nullptr;
+  g_traceTiles = tiles;
+  return g_trace + (size_t)pass * kTraceMaxTiles * 8;
+}
+void DumpTrace() {
+  const char* path = std::getenv("VRDX_TRACE_FILE");
+  if (g_trace == nullptr || path == nullptr) return;
+  (void)hipDeviceSynchronize();
+  const size_t words = 4ull * kTraceMaxTiles * 8;
+  unsigned long long* host = new unsigned long long[words];
+  if (hipMemcpy(host, g_trace, words * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+    if (FILE* f = std::fopen(path, "wb")) {
+      std::fwrite(&g_traceTiles, sizeof(g_traceTiles), 1, f);
+      for (uint32_t pass = 0; pass < 4; ++pass)
+        std::fwrite(host + (size_t)pass * kTraceMaxTiles * 8, sizeof(unsigned long long), (size_t)g_traceTiles * 8, f);
+      std::fclose(f);
+    }
+  }
+  delete[] host;
+}
+#endif
+
 inline uint8_t* BufferAddress(VkBuffer buffer, VkDeviceSize offset) {
   return reinterpret_cast<uint8_t*>(buffer) + offset;
 }
