@@ -190,6 +190,8 @@ __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t*
 constexpr int kLookBackWindow = VRDX_LOOKBACK_WINDOW;
 constexpr uint32_t kSpinLimit = 1u << 18;
 constexpr int32_t kLookBackDone = INT32_MIN;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));  // 16-byte access, 4-byte aligned
 
 template <int THREADS>
 __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t tile, int tid, uint32_t* lds,
@@ -506,22 +508,32 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   __syncthreads();
   VRDX_STAMP(5);
 
-  // ---- scatter: consecutive lanes -> consecutive addresses inside each digit run --------------
-  uint32_t digits[KV ? KPT / 4 : 1];  // key+value: digit of every scatter slot, four to a register
+  // ---- scatter: four consecutive sorted positions per lane ------------------------------------
+  // The staging buffer is sorted by digit, so the four keys of a quad almost always share their
+  // digit (runs are ~64 keys on uniform data) and go to four consecutive words: one 16-byte LDS read
+  // and one 16-byte store (4-byte aligned: gfx950 global stores need no natural alignment) instead of
+  // four of each; consecutive lanes still cover consecutive addresses.  A quad that straddles a run
+  // boundary or the ragged end falls back to single stores.
+  uint32_t digits[KV ? KPT / 4 : 1];  // key+value: the quad's four digits, for the value phase
 #pragma unroll
-  for (int j = 0; j < KPT; ++j) {
-    const uint32_t p = tid + j * THREADS;
-    uint32_t d = 0;
-    if (p < valid) {
-      const uint32_t k = sorted[p];
-      d = (k >> a.shift) & 0xFFu;
-      const uint32_t o = (kAblate & 4u) ? tileStart + p : tileOffset[d] + p;
-      a.keysOut[o] = k;
+  for (int j = 0; j < KPT / 4; ++j) {
+    const uint32_t p = 4u * (tid + j * THREADS);
+    const u32x4 k4 = *reinterpret_cast<const u32x4*>(&sorted[p]);
+    const uint32_t d0 = (k4[0] >> a.shift) & 0xFFu, d1 = (k4[1] >> a.shift) & 0xFFu;
+    const uint32_t d2 = (k4[2] >> a.shift) & 0xFFu, d3 = (k4[3] >> a.shift) & 0xFFu;
+    if (p + 3 < valid && d0 == d3) {
+      const uint32_t o = (kAblate & 4u) ? tileStart + p : tileOffset[d0] + p;
+      *reinterpret_cast<u32x4_a4*>(a.keysOut + o) = k4;
+    } else {
+      const uint32_t dd[4] = {d0, d1, d2, d3};
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (p + c < valid) a.keysOut[((kAblate & 4u) ? tileStart : tileOffset[dd[c]]) + p + c] = k4[c];
     }
     if (KV) {
-      digits[j / 4] = (j % 4 == 0) ? d : (digits[j / 4] | (d << (8 * (j % 4))));
-      // values and positions are live here: keep the scheduler from batching all KPT LDS reads
-      if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+      digits[j] = d0 | (d1 << 8) | (d2 << 16) | (d3 << 24);
+      // values and positions are live here: keep the scheduler from batching all the LDS reads
+      if (j % 2 == 1) __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (KV) {
@@ -530,12 +542,19 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
     for (int i = 0; i < KPT; ++i) sorted[(packedPos[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) {
-      const uint32_t p = tid + j * THREADS;
-      if (p < valid) {
-        const uint32_t d = (digits[j / 4] >> (8 * (j % 4))) & 0xFFu;
-        const uint32_t o = (kAblate & 4u) ? tileStart + p : tileOffset[d] + p;
-        a.valuesOut[o] = sorted[p];
+    for (int j = 0; j < KPT / 4; ++j) {
+      const uint32_t p = 4u * (tid + j * THREADS);
+      const u32x4 v4 = *reinterpret_cast<const u32x4*>(&sorted[p]);
+      const uint32_t d0 = digits[j] & 0xFFu, d3 = digits[j] >> 24;
+      if (p + 3 < valid && d0 == d3) {
+        const uint32_t o = (kAblate & 4u) ? tileStart + p : tileOffset[d0] + p;
+        *reinterpret_cast<u32x4_a4*>(a.valuesOut + o) = v4;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const uint32_t d = (digits[j] >> (8 * c)) & 0xFFu;
+          if (p + c < valid) a.valuesOut[((kAblate & 4u) ? tileStart : tileOffset[d]) + p + c] = v4[c];
+        }
       }
     }
   }
