@@ -479,8 +479,22 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   __syncthreads();  // waveHist is dead from here on: the look-back reuses it as scratch
   VRDX_STAMP(4);
 
-  // The keys' registers are free now: fetch the values; the look-back covers their latency.
-  // (after the barrier, so that they cannot be hoisted into the staging loop next to the keys)
+  // ---- decoupled look-back over the preceding tiles, then publish the inclusive prefix --------
+  uint32_t lookBackTrace = 0;
+  if (tile != 0 && !(kAblate & 1u))
+    exclusive = LookBack<THREADS>(a.statusCur, tile, tid, waveHist, a.failure, &lookBackTrace);
+  if (tid < 256) {
+    if (!lastTile)
+      StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid],
+                  (VRDX_FLAG_INCLUSIVE << VRDX_FLAG_SHIFT) | ((exclusive + count) & VRDX_VALUE_MASK));
+    tileOffset[tid] = exclusive - tileExclusive;
+  }
+  __syncthreads();
+  VRDX_STAMP(5);
+
+  // Key+value: fetch the values now; the key scatter covers their latency.  (Issued before the
+  // look-back they sit in this CU's memory queue in front of its agent-scope status reads and
+  // stretch the look-back from 6 to 9 us -- measured.)
   uint32_t val[KV ? KPT : 1];
   if (KV) {
     if (valid == TILE) {
@@ -495,18 +509,6 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
     }
   }
 
-  // ---- decoupled look-back over the preceding tiles, then publish the inclusive prefix --------
-  uint32_t lookBackTrace = 0;
-  if (tile != 0 && !(kAblate & 1u))
-    exclusive = LookBack<THREADS>(a.statusCur, tile, tid, waveHist, a.failure, &lookBackTrace);
-  if (tid < 256) {
-    if (!lastTile)
-      StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid],
-                  (VRDX_FLAG_INCLUSIVE << VRDX_FLAG_SHIFT) | ((exclusive + count) & VRDX_VALUE_MASK));
-    tileOffset[tid] = exclusive - tileExclusive;
-  }
-  __syncthreads();
-  VRDX_STAMP(5);
 
   // ---- scatter: four consecutive sorted positions per lane ------------------------------------
   // The staging buffer is sorted by digit, so the four keys of a quad almost always share their
