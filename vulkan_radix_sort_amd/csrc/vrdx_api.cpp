@@ -176,7 +176,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   // upsweep of all four passes at once
   {
     uint32_t grid = vrdx::RoundUp(elementCount, vrdx::kHistKeysPerTrip);
-    const uint32_t cap = (uint32_t)sorter->computeUnits * 2u;
+    const uint32_t cap = (uint32_t)sorter->computeUnits * vrdx::kHistWorkgroupsPerCu;
     if (grid > cap) grid = cap;
     if (grid == 0) grid = 1;
     vrdx::LaunchHistogram(stream, grid, keys, elementCount, countPtr, globalHistogram);

@@ -8,8 +8,18 @@
 
 namespace vrdx {
 
-constexpr uint32_t kHistThreads = 1024;
-constexpr uint32_t kHistCopies = 8;
+#ifndef VRDX_HIST_THREADS
+#define VRDX_HIST_THREADS 1024
+#endif
+#ifndef VRDX_HIST_COPIES
+#define VRDX_HIST_COPIES 8
+#endif
+#ifndef VRDX_HIST_WGS_PER_CU
+#define VRDX_HIST_WGS_PER_CU 2
+#endif
+constexpr uint32_t kHistThreads = VRDX_HIST_THREADS;
+constexpr uint32_t kHistCopies = VRDX_HIST_COPIES;
+constexpr uint32_t kHistWorkgroupsPerCu = VRDX_HIST_WGS_PER_CU;
 // keys one histogram workgroup handles per loop trip (kHistThreads lanes x 4 uint4 x 4 keys)
 constexpr uint32_t kHistKeysPerTrip = kHistThreads * 4 * 4;
 

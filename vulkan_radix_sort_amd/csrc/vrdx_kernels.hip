@@ -11,10 +11,12 @@
 //     histograms (the reference re-reads the keys once per pass) into the same uint[4][256] table
 //     the reference calls globalHistogram (src/vk_radix_sort.h.in:405-406).
 //   * onesweep_kernel   -- one launch per pass fuses upsweep + spine + downsweep: a tile of
-//     THREADS*KPT keys is ranked with wave64 match-any ballots, publishes its 256 digit counts as
-//     {flag,value} status words, resolves its global offsets with a decoupled look-back over the
-//     preceding tiles (agent-scope relaxed atomics: the 8 XCD L2s are not coherent), regroups keys
-//     by digit in LDS and writes them out with consecutive lanes on consecutive addresses.
+//     THREADS*KPT keys is ranked stably inside each wave64 (one returning LDS atomic per key on a
+//     wave-private counter, device-verified; 8-ballot match-any as the fallback), publishes its 256
+//     digit counts as {flag,value} status words, resolves its global offsets with a decoupled
+//     look-back over the preceding tiles (agent-scope relaxed atomics: the 8 XCD L2s are not
+//     coherent), regroups keys by digit in LDS and writes them out four at a time with consecutive
+//     lanes on consecutive addresses; values replay the permutation through the same LDS buffer.
 //   Tile ids are handed out by an atomic ticket in ARRIVAL order, so a look-back only ever waits
 //   on a tile that is already running; every spin is bounded (failure word, never a hang).
 #include <hip/hip_runtime.h>
