@@ -485,6 +485,74 @@ int Adversarial(Harness& h, int lg) {
   return failures;
 }
 
+
+// Soak: many sorts of random sizes and entropies back to back, every result checked bit for bit
+// against the oracle -- hunts rare cross-workgroup races (status hand-off, ticket, LDS ranking)
+// that a single pass over the parity battery could miss.  Two streams alternate so that sorts of
+// different sizes overlap on the device.
+int Soak(Harness& h, int seconds) {
+  std::mt19937 g(12345);
+  hipStream_t second;
+  HIP_OK(hipStreamCreate(&second));
+  const uint32_t maxN = 3u << 20;
+  const uint32_t inoutMax = Align16(maxN * 4u);
+  VrdxSorterStorageRequirements req;
+  vrdxGetSorterKeyValueStorageRequirements(h.sorter, maxN, &req);
+  uint8_t* buf[2];
+  uint8_t* sto[2];
+  for (int i = 0; i < 2; ++i) {
+    HIP_OK(hipMalloc((void**)&buf[i], (size_t)2 * inoutMax + 16));
+    HIP_OK(hipMalloc((void**)&sto[i], (size_t)req.size));
+  }
+  hipStream_t streams[2] = {h.stream, second};
+  const auto t0 = std::chrono::steady_clock::now();
+  int sorts = 0, failures = 0;
+  while (std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+    std::vector<uint32_t> k[2], v[2];
+    uint32_t n[2], inout[2];
+    bool kv[2];
+    for (int i = 0; i < 2; ++i) {
+      const uint32_t r = g();
+      n[i] = (r % 7 == 0) ? (g() % 20000) : (g() % maxN);
+      const uint32_t bits = (g() % 4 == 0) ? (g() % 33) : 32;
+      kv[i] = g() & 1;
+      k[i].resize(n[i]);
+      v[i].resize(n[i]);
+      for (auto& x : k[i]) {
+        const uint32_t y = g();
+        x = bits >= 32 ? y : (bits == 0 ? 0u : y >> (32 - bits));
+      }
+      for (uint32_t j = 0; j < n[i]; ++j) v[i][j] = j;
+      inout[i] = Align16(n[i] * 4u);
+      HIP_OK(hipMemcpyAsync(buf[i], k[i].data(), (size_t)n[i] * 4, hipMemcpyHostToDevice, streams[i]));
+      HIP_OK(hipMemcpyAsync(buf[i] + inout[i], v[i].data(), (size_t)n[i] * 4, hipMemcpyHostToDevice, streams[i]));
+    }
+    for (int i = 0; i < 2; ++i) {
+      if (kv[i])
+        vrdxCmdSortKeyValue((VkCommandBuffer)streams[i], h.sorter, n[i], (VkBuffer)buf[i], 0, (VkBuffer)buf[i], inout[i],
+                            (VkBuffer)sto[i], 0, VK_NULL_HANDLE, 0);
+      else
+        vrdxCmdSort((VkCommandBuffer)streams[i], h.sorter, n[i], (VkBuffer)buf[i], 0, (VkBuffer)sto[i], 0, VK_NULL_HANDLE, 0);
+    }
+    for (int i = 0; i < 2; ++i) {
+      HIP_OK(hipStreamSynchronize(streams[i]));
+      std::vector<uint32_t> gk(n[i]), gv(n[i]);
+      HIP_OK(hipMemcpy(gk.data(), buf[i], (size_t)n[i] * 4, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(gv.data(), buf[i] + inout[i], (size_t)n[i] * 4, hipMemcpyDeviceToHost));
+      const uint32_t status = n[i] ? vrdxHipReadStatus((VkCommandBuffer)streams[i], (VkBuffer)sto[i], 0) : 0;
+      vrdx_oracle_sort(k[i].data(), kv[i] ? v[i].data() : nullptr, n[i], nullptr);
+      const bool ok = status == 0 && gk == k[i] && (!kv[i] || gv == v[i]);
+      if (!ok) {
+        ++failures;
+        std::printf("FAIL soak sort %d n=%u kv=%d status=%u\n", sorts, n[i], (int)kv[i], status);
+      }
+      ++sorts;
+    }
+  }
+  std::printf("soak: %d sorts, %d failures\n", sorts, failures);
+  return failures;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -515,6 +583,7 @@ int main(int argc, char** argv) {
     vrdxDestroySorter(h.sorter);
     return 0;
   }
+  if (what == "soak") return Soak(h, argc > 2 ? std::atoi(argv[2]) : 30) ? 1 : 0;
   if (what == "adversarial") return Adversarial(h, argc > 2 ? std::atoi(argv[2]) : 25) ? 1 : 0;
   if (what == "bench") {
     std::vector<int> logs;

@@ -377,6 +377,16 @@ def test_native_selftest_binary(torch_mod):
     assert "0 failures" in r.stdout
 
 
+def test_native_soak_overlapping_sorts(torch_mod):
+    """20 s of randomized sorts (sizes up to 3M, random entropy, keys / key+value) alternating on two
+    streams, each checked bit for bit against the oracle: hunts rare cross-workgroup races."""
+    exe = os.path.join(ROOT, "tests", "native", "vrdx_selftest")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.dirname(exe)], check=True)
+    r = subprocess.run([exe, "soak", "20"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and ", 0 failures" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("config", ["1024x16", "512x32", "1024x8", "512x16", "512x24"])
 def test_other_tile_configs(torch_mod, oracle, config):
     """Every compiled tile geometry is parity-clean, not only the default one."""
