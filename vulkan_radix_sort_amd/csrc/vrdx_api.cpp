@@ -135,6 +135,20 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   const bool keyValue = valuesBuffer != nullptr;
   if (elementCount > VRDX_MAX_ELEMENTS) elementCount = VRDX_MAX_ELEMENTS;
 
+  // Launches go to the sorter's device (a Vulkan command buffer belongs to one device too); the
+  // calling thread's current device is put back afterwards.
+  struct DeviceScope {
+    int previous = -1;
+    explicit DeviceScope(int wanted) {
+      int current = -1;
+      if (hipGetDevice(&current) == hipSuccess && current != wanted && hipSetDevice(wanted) == hipSuccess)
+        previous = current;
+    }
+    ~DeviceScope() {
+      if (previous >= 0) (void)hipSetDevice(previous);
+    }
+  } deviceScope(sorter->device);
+
   const int configIndex = ConfigIndex(keyValue, elementCount);
   const uint32_t tileKeys = vrdx::kTileConfigs[configIndex].tileKeys();
   const vrdx::StorageLayout layout =
