@@ -28,7 +28,7 @@ struct TileConfig {
   int keysPerThread;
   uint32_t tileKeys() const { return (uint32_t)threads * (uint32_t)keysPerThread; }
 };
-constexpr int kNumTileConfigs = 7;
+constexpr int kNumTileConfigs = 6;
 extern const TileConfig kTileConfigs[kNumTileConfigs];
 
 struct OnesweepArgs {

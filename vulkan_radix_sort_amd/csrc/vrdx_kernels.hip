@@ -210,7 +210,9 @@ __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t ti
   uint32_t spins = 0;
   uint32_t traceTrips = 0, traceRows = 0;  // thread 0 only, reported to tools/trace.sh builds
   bool done = g != 0;  // only group 0 owns the per-digit state
+  uint32_t* const vote = info + GROUPS * 256;  // [2]: "some digit is still walking", by trip parity
   if (g == 0) pos[d] = (int32_t)tile - 1;
+  if (tid < 2) vote[tid] = 0;
   __syncthreads();
 
   for (;;) {
@@ -267,10 +269,15 @@ __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t ti
       pos[d] = done ? kLookBackDone : j - (int32_t)advance;
       traceRows += advance;
     }
-    ++traceTrips;
     // One barrier + vote: this trip's sum/info are consumed and pos is updated before the next
-    // trip touches them.
-    if (__syncthreads_and(done ? 1 : 0)) break;
+    // trip touches them.  (A hand-made vote: __syncthreads_and would add static LDS and push two
+    // 80 KiB workgroups over the CU's 160 KiB.)
+    if (!done) vote[traceTrips & 1u] = 1;
+    __syncthreads();
+    const bool again = vote[traceTrips & 1u] != 0;
+    ++traceTrips;
+    if (!again) break;
+    if (tid == 0) vote[traceTrips & 1u] = 0;
   }
   if (traceTripsRows != nullptr && tid == 0) *traceTripsRows = (traceTrips << 16) | (traceRows & 0xFFFFu);
   return exclusive;
@@ -351,9 +358,12 @@ __device__ __forceinline__ void RankAtomic(const uint32_t (&key)[KPT], uint32_t 
 // at T = 16384: one workgroup per CU and nothing to overlap its waits with).
 template <int THREADS, int KPT, bool KV>
 constexpr size_t OnesweepLdsWords() {
-  // staging buffer (keys, then values) | per-wave digit counters (later: look-back scratch) |
-  // per-digit scatter offsets | scan scratch + ticket
-  return (size_t)THREADS * KPT + (size_t)(THREADS / 64) * 256 + 256 + 16;
+  // staging buffer (keys, then values) | per-wave digit counters.  Everything else lives inside
+  // those two at times when they are idle: ticket + scan scratch at the front of the staging
+  // buffer (before the regroup), look-back scratch at the bottom and the per-digit scatter offsets
+  // in the top 256 words of the counters (after the regroup).  1024 x 16 is then exactly 80 KiB:
+  // two workgroups per CU.
+  return (size_t)THREADS * KPT + (size_t)(THREADS / 64) * 256;
 }
 
 // Waves per SIMD the register allocation must leave room for: two workgroups per CU whenever the
@@ -368,16 +378,17 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   constexpr int WAVES = THREADS / 64;
   constexpr uint32_t TILE = THREADS * KPT;
   static_assert(THREADS >= 256 && THREADS % 256 == 0, "one thread per digit, whole look-back groups");
-  static_assert(WAVES * 256 >= 256 * (1 + 2 * (THREADS / 256)), "look-back scratch aliases the wave counters");
+  static_assert(WAVES * 256 >= 256 * (1 + 2 * (THREADS / 256)) + 2 + 256,
+                "look-back scratch and the scatter offsets alias the wave counters");
 
   static_assert(KPT % 4 == 0, "digits of the value phase are packed four to a register");
 
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* const sorted = smem;                                    // TILE: keys (then values) regrouped by digit
   uint32_t* const waveHist = smem + TILE;                           // WAVES x 256, then look-back scratch
-  uint32_t* const tileOffset = waveHist + WAVES * 256;              // 256: global base - tile-local base
-  uint32_t* const scanScratch = tileOffset + 256;                   // 8
-  uint32_t* const misc = scanScratch + 8;                           // [0] ticket
+  uint32_t* const tileOffset = waveHist + (WAVES - 1) * 256;        // 256: global base - tile-local base (after the regroup)
+  uint32_t* const scanScratch = smem;                               // 8   (before the regroup)
+  uint32_t* const misc = smem + 8;                                  // [0] ticket (before the regroup)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -649,7 +660,7 @@ static void LaunchConfig(hipStream_t stream, uint32_t grid, bool keyValue, bool 
 }
 
 const TileConfig kTileConfigs[kNumTileConfigs] = {
-    {512, 16}, {1024, 16}, {512, 32}, {1024, 8}, {256, 32}, {512, 24}, {512, 28},
+    {512, 16}, {1024, 16}, {512, 32}, {1024, 8}, {512, 24}, {512, 28},
 };
 
 hipError_t PrepareKernels(int configIndex) {
@@ -658,9 +669,8 @@ hipError_t PrepareKernels(int configIndex) {
     case 1: return PrepareConfig<1024, 16>();
     case 2: return PrepareConfig<512, 32>();
     case 3: return PrepareConfig<1024, 8>();
-    case 4: return PrepareConfig<256, 32>();
-    case 5: return PrepareConfig<512, 24>();
-    case 6: return PrepareConfig<512, 28>();
+    case 4: return PrepareConfig<512, 24>();
+    case 5: return PrepareConfig<512, 28>();
     default: return hipErrorInvalidValue;
   }
 }
@@ -693,9 +703,8 @@ void LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool key
     case 1: LaunchConfig<1024, 16>(stream, grid, keyValue, atomicRank, args); break;
     case 2: LaunchConfig<512, 32>(stream, grid, keyValue, atomicRank, args); break;
     case 3: LaunchConfig<1024, 8>(stream, grid, keyValue, atomicRank, args); break;
-    case 4: LaunchConfig<256, 32>(stream, grid, keyValue, atomicRank, args); break;
-    case 5: LaunchConfig<512, 24>(stream, grid, keyValue, atomicRank, args); break;
-    case 6: LaunchConfig<512, 28>(stream, grid, keyValue, atomicRank, args); break;
+    case 4: LaunchConfig<512, 24>(stream, grid, keyValue, atomicRank, args); break;
+    case 5: LaunchConfig<512, 28>(stream, grid, keyValue, atomicRank, args); break;
     default: break;
   }
 }
