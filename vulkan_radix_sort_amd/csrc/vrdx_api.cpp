@@ -64,9 +64,10 @@ int ForcedConfigIndex() {
 int ConfigIndex(bool keyValue, uint32_t elementCount) {
   const int forced = ForcedConfigIndex();
   if (forced >= 0) return forced;
-  if (elementCount <= (1u << 19)) return 3;                          // 1024 x 8   (T = 8192)
-  if (elementCount <= (keyValue ? 6u : 12u) * (1u << 20)) return 1;  // 1024 x 16  (T = 16384, 16 waves)
-  return 2;                                                          // 512 x 32   (T = 16384, 2 workgroups / CU)
+  if (elementCount <= (1u << 19)) return 3;   // 1024 x 8   (T = 8192: more tiles for 256 CUs)
+  if (elementCount <= 24u << 20) return 1;    // 1024 x 16  (T = 16384, two 16-wave workgroups per CU)
+  (void)keyValue;
+  return 2;                                   // 512 x 32   (T = 16384, two 8-wave workgroups per CU)
 }
 
 #ifdef VRDX_TRACE
