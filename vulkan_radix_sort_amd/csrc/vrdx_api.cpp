@@ -172,7 +172,9 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   }
 
   // Clear count/tickets/failure word, the 4x256 global histogram (reference :382) and status
-  // region 0 in one fill; then store the element count where the reference keeps it (:368-379).
+  // region 0 in one fill.  Indirect: also copy the device-side count to where the reference keeps
+  // it (:368-379); the kernels themselves read it straight from the caller's buffer.  (Direct: the
+  // count travels as a kernel argument, the slot stays 0 -- storage contents are scratch.)
   (void)hipMemsetAsync(storage, 0, layout.clearBytes, stream);
   DebugCheck("hipMemsetAsync(state)");
   if (countPtr != nullptr)
