@@ -387,7 +387,7 @@ def test_native_soak_overlapping_sorts(torch_mod):
     assert r.returncode == 0 and ", 0 failures" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("config", ["1024x16", "512x32", "1024x8", "512x16", "512x24"])
+@pytest.mark.parametrize("config", ["1024x16", "512x32", "1024x8", "512x16", "512x24", "1024x32"])
 def test_other_tile_configs(torch_mod, oracle, config):
     """Every compiled tile geometry is parity-clean, not only the default one."""
     exe = os.path.join(ROOT, "tests", "native", "vrdx_selftest")

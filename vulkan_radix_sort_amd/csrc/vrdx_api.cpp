@@ -43,9 +43,10 @@ int DeviceOrdinalFromHandle(const void* handle, int* ordinal) {
 }
 
 // Tile geometry by problem size, measured on MI355X (profiles/r01_native_sweep_n.txt): small sorts
-// want many small tiles (parallelism across 256 CUs), large sorts want 16384-key tiles of 512
-// threads (fewer look-back rows per key, two workgroups per CU).
-//   index into vrdx::kTileConfigs: 0 = 512x16, 1 = 1024x16, 2 = 512x32, 3 = 1024x8, ...
+// want many small tiles (parallelism across 256 CUs); beyond that throughput grows monotonically
+// with the tile (fewer look-backs per key, longer digit runs), up to the 32768 keys whose staging
+// buffer still fits the CU's LDS.
+//   index into vrdx::kTileConfigs: 0 = 512x16, 1 = 1024x16, 2 = 512x32, 3 = 1024x8, ... 7 = 1024x32
 int ForcedConfigIndex() {
   static const int forced = [] {
     const char* env = std::getenv("VRDX_TILE_CONFIG");  // e.g. "512x16": one geometry for everything (tuning/testing)
@@ -64,10 +65,11 @@ int ForcedConfigIndex() {
 int ConfigIndex(bool keyValue, uint32_t elementCount) {
   const int forced = ForcedConfigIndex();
   if (forced >= 0) return forced;
+  (void)keyValue;                             // the same break points serve keys-only and key+value
   if (elementCount <= (1u << 19)) return 3;   // 1024 x 8   (T = 8192: more tiles for 256 CUs)
-  if (elementCount <= 24u << 20) return 1;    // 1024 x 16  (T = 16384, two 16-wave workgroups per CU)
-  (void)keyValue;
-  return 2;                                   // 512 x 32   (T = 16384, two 8-wave workgroups per CU)
+  if (elementCount <= 6u << 20) return 1;     // 1024 x 16  (T = 16384, two workgroups per CU)
+  return 7;                                   // 1024 x 32  (T = 32768, one 16-wave workgroup per CU:
+                                              //             half the look-backs per key again)
 }
 
 #ifdef VRDX_TRACE

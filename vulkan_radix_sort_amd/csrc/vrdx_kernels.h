@@ -28,7 +28,7 @@ struct TileConfig {
   int keysPerThread;
   uint32_t tileKeys() const { return (uint32_t)threads * (uint32_t)keysPerThread; }
 };
-constexpr int kNumTileConfigs = 6;
+constexpr int kNumTileConfigs = 8;
 extern const TileConfig kTileConfigs[kNumTileConfigs];
 
 struct OnesweepArgs {

@@ -370,7 +370,11 @@ constexpr size_t OnesweepLdsWords() {
 // LDS footprint allows two (every geometry except key+value tiles wider than 16384).
 template <int THREADS, int KPT>
 constexpr int MinWavesPerSimd() {
-  return (OnesweepLdsWords<THREADS, KPT, false>() * 4 * 2 <= 160 * 1024) ? 2 * THREADS / 256 : THREADS / 256;
+  // as many workgroups per CU as the LDS footprint allows (at most 8 waves per SIMD)
+  constexpr size_t lds = OnesweepLdsWords<THREADS, KPT, false>() * 4;
+  constexpr int workgroups = (int)((160 * 1024) / lds);
+  constexpr int waves = workgroups * THREADS / 256;
+  return waves > 8 ? 8 : (waves < 1 ? 1 : waves);
 }
 
 template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK>
@@ -660,7 +664,7 @@ static void LaunchConfig(hipStream_t stream, uint32_t grid, bool keyValue, bool 
 }
 
 const TileConfig kTileConfigs[kNumTileConfigs] = {
-    {512, 16}, {1024, 16}, {512, 32}, {1024, 8}, {512, 24}, {512, 28},
+    {512, 16}, {1024, 16}, {512, 32}, {1024, 8}, {512, 24}, {512, 28}, {512, 20}, {1024, 32},
 };
 
 hipError_t PrepareKernels(int configIndex) {
@@ -671,6 +675,8 @@ hipError_t PrepareKernels(int configIndex) {
     case 3: return PrepareConfig<1024, 8>();
     case 4: return PrepareConfig<512, 24>();
     case 5: return PrepareConfig<512, 28>();
+    case 6: return PrepareConfig<512, 20>();
+    case 7: return PrepareConfig<1024, 32>();
     default: return hipErrorInvalidValue;
   }
 }
@@ -705,6 +711,8 @@ void LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool key
     case 3: LaunchConfig<1024, 8>(stream, grid, keyValue, atomicRank, args); break;
     case 4: LaunchConfig<512, 24>(stream, grid, keyValue, atomicRank, args); break;
     case 5: LaunchConfig<512, 28>(stream, grid, keyValue, atomicRank, args); break;
+    case 6: LaunchConfig<512, 20>(stream, grid, keyValue, atomicRank, args); break;
+    case 7: LaunchConfig<1024, 32>(stream, grid, keyValue, atomicRank, args); break;
     default: break;
   }
 }
