@@ -571,6 +571,11 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 3; ++rep) {
       std::vector<uint32_t> v;
       auto k = Mt(n, rep + 1, 32, &v);
+      const std::string pattern = argc > 4 ? argv[4] : "uniform";
+      if (pattern == "ascending")
+        for (uint32_t i = 0; i < n; ++i) k[i] = i;
+      else if (pattern == "equal")
+        std::fill(k.begin(), k.end(), 0x12345678u);
       HIP_OK(hipMemcpy(h.dKeys, k.data(), (size_t)n * 4, hipMemcpyHostToDevice));
       HIP_OK(hipMemcpy(h.dKeys + inout, v.data(), (size_t)n * 4, hipMemcpyHostToDevice));
       if (kv)
