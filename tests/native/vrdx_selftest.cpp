@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -414,6 +415,51 @@ void Bench(Harness& h, const std::vector<int>& logs) {
 }
 
 
+// Timing-only size sweep for tile-geometry break points: N = 2^(lo + i*(hi-lo)/(points-1)), one
+// random key/value set generated once (each run re-uploads the first N), median of 7 event-bracketed
+// sorts without a query pool.
+void Sweep(Harness& h, double lo, double hi, int points, bool kv) {
+  const uint32_t nMax = (uint32_t)std::llround(std::pow(2.0, hi));
+  std::vector<uint32_t> v;
+  auto k = Mt(nMax, 7, 32, &v);
+  VrdxSorterStorageRequirements req;
+  vrdxGetSorterKeyValueStorageRequirements(h.sorter, nMax, &req);
+  const uint32_t inoutMax = Align16(nMax * 4u);
+  h.reserve((size_t)2 * inoutMax + 16, (size_t)req.size);
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0));
+  HIP_OK(hipEventCreate(&e1));
+  std::printf("%-10s %-5s %10s %12s\n", "n", "sort", "gpu_ms", "GItems/s");
+  for (int i = 0; i < points; ++i) {
+    const double lg = points > 1 ? lo + (hi - lo) * i / (points - 1) : lo;
+    const uint32_t n = (uint32_t)std::llround(std::pow(2.0, lg));
+    const uint32_t inout = Align16(n * 4u);
+    std::vector<uint64_t> t;
+    for (int runIdx = 0; runIdx < 8; ++runIdx) {
+      HIP_OK(hipMemcpy(h.dKeys, k.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+      if (kv) HIP_OK(hipMemcpy(h.dKeys + inout, v.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+      HIP_OK(hipDeviceSynchronize());
+      HIP_OK(hipEventRecord(e0, h.stream));
+      if (kv)
+        vrdxCmdSortKeyValue((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dKeys, inout,
+                            (VkBuffer)h.dStorage, 0, VK_NULL_HANDLE, 0);
+      else
+        vrdxCmdSort((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dStorage, 0, VK_NULL_HANDLE, 0);
+      HIP_OK(hipEventRecord(e1, h.stream));
+      HIP_OK(hipStreamSynchronize(h.stream));
+      float msf = 0;
+      HIP_OK(hipEventElapsedTime(&msf, e0, e1));
+      if (runIdx > 0) t.push_back((uint64_t)(msf * 1e6));
+    }
+    const double ms = Median(t) / 1e6;
+    std::printf("%-10u %-5s %10.4f %12.3f\n", n, kv ? "kv" : "keys", ms, n / (ms * 1e-3) / 1e9);
+    std::fflush(stdout);
+  }
+  HIP_OK(hipEventDestroy(e0));
+  HIP_OK(hipEventDestroy(e1));
+}
+
+
 // BASELINE.json configs[3]: N = 2^25 adversarial keys (all-equal, all-0xFFFFFFFF, descending,
 // few-distinct) against uniform random; values = iota, parity checked with the oracle for the
 // stable permutation, then timed (median of 5, data re-uploaded before every run).
@@ -588,6 +634,11 @@ int main(int argc, char** argv) {
     vrdxDestroySorter(h.sorter);
     return 0;
   }
+  if (what == "sweep") {  // sweep <lo log2> <hi log2> <points> [keys|kv]
+    Sweep(h, argc > 2 ? std::atof(argv[2]) : 22.0, argc > 3 ? std::atof(argv[3]) : 26.0, argc > 4 ? std::atoi(argv[4]) : 17,
+          argc > 5 && std::string(argv[5]) == "kv");
+    return 0;
+  }
   if (what == "soak") return Soak(h, argc > 2 ? std::atoi(argv[2]) : 30) ? 1 : 0;
   if (what == "adversarial") return Adversarial(h, argc > 2 ? std::atoi(argv[2]) : 25) ? 1 : 0;
   if (what == "bench") {
@@ -597,6 +648,6 @@ int main(int argc, char** argv) {
     Bench(h, logs);
     return 0;
   }
-  std::fprintf(stderr, "usage: %s parity|quick|bench [log2n...]|adversarial [log2n]|trace\n", argv[0]);
+  std::fprintf(stderr, "usage: %s parity|quick|bench [log2n...]|adversarial [log2n]|soak [s]|sweep lo hi points [kv]|trace\n", argv[0]);
   return 64;
 }

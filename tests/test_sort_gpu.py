@@ -298,6 +298,26 @@ def test_capturable_into_a_hip_graph(torch_mod, sorter, oracle):
         assert sorter.read_status(torch.cuda.current_stream().cuda_stream, storage.data_ptr(), 0) == 0
 
 
+# one size inside every regime of the size-adaptive tile selection (ConfigIndex in vrdx_api.cpp; f =
+# N / (256 CUs * 32768)): 1024x8 | 1024x16 | 1024x32 | two-sub-tile 1024x32x2 | 1024x16 between
+# rounds | ... -- all ragged (odd) sizes
+BREAK_POINT_SIZES = [int(f * (1 << 23)) + 12345 for f in (0.10, 0.20, 0.40, 0.58, 0.80, 1.2, 1.6, 1.99, 2.3)] + \
+                    [(1 << 24), (1 << 24) + 1, (1 << 23) + 1]
+
+
+@pytest.mark.parametrize("n", BREAK_POINT_SIZES)
+def test_every_size_regime_matches_oracle(torch_mod, sorter, oracle, n):
+    """Keys-only and key+value (values = iota: the permutation itself) are bit-exact in every regime
+    of the tile-geometry selection, including the two-sub-tile kernel (8.4 M < N <= 16.8 M keys-only)."""
+    k, _ = oracle.generate(3, n, 32)
+    iota = np.arange(n, dtype=np.uint32)
+    ek, ep, _ = oracle.sort(k, iota)
+    gk, _ = gpu_sort(torch_mod, sorter, k)
+    assert np.array_equal(gk, ek)
+    gk, gp = gpu_sort(torch_mod, sorter, k, iota)
+    assert np.array_equal(gk, ek) and np.array_equal(gp, ep)
+
+
 @pytest.mark.parametrize("seed", [1, 2])
 def test_full_size_2pow25_properties_and_golden_checksum(torch_mod, sorter, oracle, golden, seed):
     """BASELINE.json configs[1] and [2]: N = 2^25 uniform-random u32, keys-only and key+value."""
@@ -387,7 +407,7 @@ def test_native_soak_overlapping_sorts(torch_mod):
     assert r.returncode == 0 and ", 0 failures" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("config", ["1024x16", "512x32", "1024x8", "512x16", "512x24", "1024x32"])
+@pytest.mark.parametrize("config", ["1024x16", "512x32", "1024x8", "512x16", "512x24", "1024x32", "1024x32x2", "512x32x2"])
 def test_other_tile_configs(torch_mod, oracle, config):
     """Every compiled tile geometry is parity-clean, not only the default one."""
     exe = os.path.join(ROOT, "tests", "native", "vrdx_selftest")

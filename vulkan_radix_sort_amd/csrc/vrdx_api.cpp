@@ -10,6 +10,7 @@
 // 2 transfers + 12 dispatches + 12 barriers.
 #include <hip/hip_runtime_api.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -42,18 +43,21 @@ int DeviceOrdinalFromHandle(const void* handle, int* ordinal) {
   return 0;
 }
 
-// Tile geometry by problem size, measured on MI355X (profiles/r01_native_sweep_n.txt): small sorts
-// want many small tiles (parallelism across 256 CUs); beyond that throughput grows monotonically
-// with the tile (fewer look-backs per key, longer digit runs), up to the 32768 keys whose staging
-// buffer still fits the CU's LDS.
-//   index into vrdx::kTileConfigs: 0 = 512x16, 1 = 1024x16, 2 = 512x32, 3 = 1024x8, ... 7 = 1024x32
+// "1024x32", or "1024x32x2" for the two-sub-tile kernel
+void ConfigName(const vrdx::TileConfig& c, char* out, size_t size) {
+  if (c.subTiles == 1)
+    std::snprintf(out, size, "%dx%d", c.threads, c.keysPerThread);
+  else
+    std::snprintf(out, size, "%dx%dx%d", c.threads, c.keysPerThread, c.subTiles);
+}
+
 int ForcedConfigIndex() {
   static const int forced = [] {
     const char* env = std::getenv("VRDX_TILE_CONFIG");  // e.g. "512x16": one geometry for everything (tuning/testing)
     if (env == nullptr) return -1;
     for (int i = 0; i < vrdx::kNumTileConfigs; ++i) {
       char name[32];
-      std::snprintf(name, sizeof(name), "%dx%d", vrdx::kTileConfigs[i].threads, vrdx::kTileConfigs[i].keysPerThread);
+      ConfigName(vrdx::kTileConfigs[i], name, sizeof(name));
       if (std::strcmp(env, name) == 0) return i;
     }
     std::fprintf(stderr, "vrdx-hip: unknown VRDX_TILE_CONFIG '%s', using the defaults\n", env);
@@ -62,14 +66,41 @@ int ForcedConfigIndex() {
   return forced;
 }
 
-int ConfigIndex(bool keyValue, uint32_t elementCount) {
+// Tile geometry by problem size, measured on MI355X (tools: `vrdx_selftest sweep`, tables in
+// profiles/r01_sweep_*.txt).  Three regimes:
+//  * small sorts want many small tiles (parallelism across the CUs; six launches cost ~45 us);
+//  * beyond that throughput grows with the tile (fewer look-backs per key, longer digit runs) up to
+//    the 32768 keys whose staging buffer fits the CU's LDS ONCE -- so these tiles run one workgroup
+//    per CU in lock-step ROUNDS of computeUnits tiles, and a sort whose tile count is just above a
+//    multiple of the CU count pays for a whole extra round.  f below is the size in such rounds.
+//    16384-key tiles (two workgroups per CU) degrade gracefully in a partial round, so they win in
+//    the lower part of each round interval while the rounds are few;
+//  * the two-sub-tile kernel (65536 keys, keys-only) halves the rounds again: best when f is at or
+//    just below 2 or 4.
+enum : int { kCfg1024x16 = 1, kCfg1024x8 = 3, kCfg1024x32 = 7, kCfg1024x32x2 = 8 };
+
+int ConfigIndex(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount) {
   const int forced = ForcedConfigIndex();
   if (forced >= 0) return forced;
-  (void)keyValue;                             // the same break points serve keys-only and key+value
-  if (elementCount <= (1u << 19)) return 3;   // 1024 x 8   (T = 8192: more tiles for 256 CUs)
-  if (elementCount <= 6u << 20) return 1;     // 1024 x 16  (T = 16384, two workgroups per CU)
-  return 7;                                   // 1024 x 32  (T = 32768, one 16-wave workgroup per CU:
-                                              //             half the look-backs per key again)
+  const double f = (double)elementCount / ((double)sorter->computeUnits * 32768.0);
+  const double intoRound = f - std::floor(f);  // 0 = exactly full rounds
+  if (keyValue) {
+    if (f <= 0.25) return kCfg1024x8;
+    if (f <= 0.53) return kCfg1024x16;
+    if (f <= 1.0) return kCfg1024x32;
+    if (f <= 4.0 && intoRound > 0.0 && intoRound <= 0.45) return kCfg1024x16;
+    return kCfg1024x32;
+  }
+  if (f <= 0.13) return kCfg1024x8;
+  if (f <= 0.6) return kCfg1024x16;
+  if (f <= 1.0) return kCfg1024x32;
+  // the two-sub-tile kernel holds two sub-tiles' keys in registers: only with the one-atomic ranking
+  const int pair = sorter->atomicRank ? kCfg1024x32x2 : kCfg1024x32;
+  if (f <= 2.0) return pair;
+  if (f <= 3.6) return kCfg1024x16;
+  if (f <= 4.0) return pair;
+  if (f <= 4.5) return kCfg1024x16;
+  return kCfg1024x32;
 }
 
 #ifdef VRDX_TRACE
@@ -152,7 +183,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     }
   } deviceScope(sorter->device);
 
-  const int configIndex = ConfigIndex(keyValue, elementCount);
+  const int configIndex = ConfigIndex(sorter, keyValue, elementCount);
   const uint32_t tileKeys = vrdx::kTileConfigs[configIndex].tileKeys();
   const vrdx::StorageLayout layout =
       vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, tileKeys);
@@ -304,7 +335,7 @@ void vrdxGetSorterStorageRequirements(VrdxSorter sorter, uint32_t maxElementCoun
                                       VrdxSorterStorageRequirements* requirements) {
   const vrdx::StorageLayout layout =
       vrdx::MakeLayout(maxElementCount, sorter->minStorageBufferOffsetAlignment,
-                       vrdx::kTileConfigs[ConfigIndex(false, maxElementCount)].tileKeys());
+                       vrdx::kTileConfigs[ConfigIndex(sorter, false, maxElementCount)].tileKeys());
   requirements->size = layout.keysOnlySize;
   requirements->usage = VK_BUFFER_USAGE_STORAGE_BUFFER_BIT | VK_BUFFER_USAGE_TRANSFER_DST_BIT;
 }
@@ -313,7 +344,7 @@ void vrdxGetSorterKeyValueStorageRequirements(VrdxSorter sorter, uint32_t maxEle
                                               VrdxSorterStorageRequirements* requirements) {
   const vrdx::StorageLayout layout =
       vrdx::MakeLayout(maxElementCount, sorter->minStorageBufferOffsetAlignment,
-                       vrdx::kTileConfigs[ConfigIndex(true, maxElementCount)].tileKeys());
+                       vrdx::kTileConfigs[ConfigIndex(sorter, true, maxElementCount)].tileKeys());
   requirements->size = layout.keyValueSize;
   requirements->usage = VK_BUFFER_USAGE_STORAGE_BUFFER_BIT | VK_BUFFER_USAGE_TRANSFER_DST_BIT;
 }
@@ -418,11 +449,17 @@ uint32_t vrdxHipReadStatus(VkCommandBuffer commandBuffer, VkBuffer storageBuffer
 
 const char* vrdxHipVersionString(void) {
   static char text[128];
-  const vrdx::TileConfig& k = vrdx::kTileConfigs[ConfigIndex(false, 1u << 25)];
-  const vrdx::TileConfig& kv = vrdx::kTileConfigs[ConfigIndex(true, 1u << 25)];
-  std::snprintf(text, sizeof(text), "vrdx-hip %d.%d.%d gfx950 tiles at 2^25: keys=%dx%d key-value=%dx%d%s",
-                VRDX_VERSION_MAJOR, VRDX_VERSION_MINOR, VRDX_VERSION_PATCH, k.threads, k.keysPerThread, kv.threads,
-                kv.keysPerThread, ForcedConfigIndex() >= 0 ? " (forced)" : " (size-adaptive)");
+  VrdxSorter_T nominal;  // an MI355X: 256 CUs, lane-ordered LDS atomics
+  nominal.computeUnits = 256;
+  nominal.atomicRank = true;
+  const vrdx::TileConfig& k = vrdx::kTileConfigs[ConfigIndex(&nominal, false, 1u << 25)];
+  const vrdx::TileConfig& kv = vrdx::kTileConfigs[ConfigIndex(&nominal, true, 1u << 25)];
+  char kName[32], kvName[32];
+  ConfigName(k, kName, sizeof(kName));
+  ConfigName(kv, kvName, sizeof(kvName));
+  std::snprintf(text, sizeof(text), "vrdx-hip %d.%d.%d gfx950 tiles at 2^25: keys=%s key-value=%s%s",
+                VRDX_VERSION_MAJOR, VRDX_VERSION_MINOR, VRDX_VERSION_PATCH, kName, kvName,
+                ForcedConfigIndex() >= 0 ? " (forced)" : " (size-adaptive)");
   return text;
 }
 

@@ -26,9 +26,10 @@ constexpr uint32_t kHistKeysPerTrip = kHistThreads * 4 * 4;
 struct TileConfig {
   int threads;
   int keysPerThread;
-  uint32_t tileKeys() const { return (uint32_t)threads * (uint32_t)keysPerThread; }
+  int subTiles;  // 1: onesweep_kernel; 2: onesweep_pair_kernel (two sub-tiles per workgroup and status row)
+  uint32_t tileKeys() const { return (uint32_t)threads * (uint32_t)keysPerThread * (uint32_t)subTiles; }
 };
-constexpr int kNumTileConfigs = 8;
+constexpr int kNumTileConfigs = 10;
 extern const TileConfig kTileConfigs[kNumTileConfigs];
 
 struct OnesweepArgs {

@@ -86,8 +86,42 @@ __device__ __forceinline__ uint32_t LanesBelow(uint64_t mask) {
                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global
+// load and store the wave has in flight (s_waitcnt vmcnt(0)): the scattered stores of the key phase,
+// prefetched keys/values.  Nothing in these kernels hands GLOBAL data from one wave to another
+// through a barrier (status words are agent-scope atomics with their own flag), so the onesweep
+// kernels use this one throughout.
+__device__ __forceinline__ void LdsBarrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// Wave-striped load of KPT words per lane: out[i] = base[first + 64 * i] (pad where the index is
+// >= n).  The byte offset is a 32-bit value (N < 2^30) added to the 64-bit base, which lets the
+// compiler use ONE offset register plus immediates for all the loads (SGPR base + VGPR offset +
+// imm) instead of a 64-bit address pair per load -- 60 registers that the two-sub-tile kernel
+// does not have.
+template <int KPT>
+__device__ __forceinline__ void LoadStriped(const uint32_t* base, uint32_t first, uint32_t n, bool full,
+                                            uint32_t pad, uint32_t (&out)[KPT]) {
+  const char* const bytes = reinterpret_cast<const char*>(base);
+  const uint32_t offset = first * 4u;
+  if (full) {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i)
+      out[i] = *reinterpret_cast<const uint32_t*>(bytes + ((uint64_t)offset + (uint64_t)(i * 256)));
+  } else {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i)
+      out[i] = first + i * 64 < n
+                   ? *reinterpret_cast<const uint32_t*>(bytes + ((uint64_t)offset + (uint64_t)(i * 256)))
+                   : pad;
+  }
+}
+
 // Exclusive scan of one value per thread over threads 0..255 (4 waves); other threads pass 0 and
-// ignore the result.  Contains one __syncthreads(): every thread of the block must call it.
+// ignore the result.  Contains one barrier: every thread of the block must call it.
 __device__ __forceinline__ uint32_t BlockExclusiveScan256(uint32_t v, uint32_t* scratch4, int tid) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -98,7 +132,7 @@ __device__ __forceinline__ uint32_t BlockExclusiveScan256(uint32_t v, uint32_t* 
     if (lane >= o) x += y;
   }
   if (wave < 4 && lane == 63) scratch4[wave] = x;
-  __syncthreads();
+  LdsBarrier();
   uint32_t add = 0;
   if (wave < 4) {
 #pragma unroll
@@ -213,7 +247,7 @@ __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t ti
   uint32_t* const vote = info + GROUPS * 256;  // [2]: "some digit is still walking", by trip parity
   if (g == 0) pos[d] = (int32_t)tile - 1;
   if (tid < 2) vote[tid] = 0;
-  __syncthreads();
+  LdsBarrier();
 
   for (;;) {
     const int32_t j = pos[d];
@@ -244,7 +278,7 @@ __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t ti
       sum[g * 256 + d] = partial;
       info[g * 256 + d] = consumed | (hit << 8);
     }
-    __syncthreads();
+    LdsBarrier();
     if (g == 0 && !done) {
       uint32_t advance = 0;
 #pragma unroll
@@ -273,7 +307,7 @@ __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t ti
     // trip touches them.  (A hand-made vote: __syncthreads_and would add static LDS and push two
     // 80 KiB workgroups over the CU's 160 KiB.)
     if (!done) vote[traceTrips & 1u] = 1;
-    __syncthreads();
+    LdsBarrier();
     const bool again = vote[traceTrips & 1u] != 0;
     ++traceTrips;
     if (!again) break;
@@ -344,7 +378,10 @@ __device__ __forceinline__ void RankAtomic(const uint32_t (&key)[KPT], uint32_t 
     for (int c = 0; c < CHUNK; ++c) {
       if (uniform[c]) r[c] = __builtin_amdgcn_readfirstlane(r[c]) + lane;
       if (PACKED) {
-        if (c % 2 == 1) out[(base + c) / 2] = r[c - 1] | (r[c] << 16);
+        if (c % 2 == 1) {
+          out[(base + c) / 2] = r[c - 1] | (r[c] << 16);
+          asm volatile("" : "+v"(out[(base + c) / 2]));  // pack now, not when first used
+        }
       } else {
         out[base + c] = r[c];
       }
@@ -370,6 +407,50 @@ __device__ __forceinline__ uint32_t StagingSlot(uint32_t p) {
 #else
   return p ^ ((p >> (kLog - 2)) & 0x3Cu);
 #endif
+}
+
+// Regroup: sorted[StagingSlot(rank + waveBase[digit])] = key, eight keys at a time -- the eight
+// counter reads are issued together and only then the eight stores (LDS reads and writes of one
+// array cannot be reordered by the compiler, so a read-store-read-store source order costs a full
+// LDS round trip per key).  PACKED ranks come two to a register; with KEEP the physical slots are
+// returned packed the same way (key+value stages the values through them).
+template <int KPT, uint32_t STAGE, bool PACKED, bool KEEP>
+__device__ __forceinline__ void RegroupKeys(const uint32_t (&key)[KPT], const uint32_t (&rank)[PACKED ? KPT / 2 : KPT],
+                                            uint32_t shift, const uint32_t* waveBase, uint32_t* sorted,
+                                            uint32_t (&slots)[KEEP ? KPT / 2 : 1]) {
+  constexpr int CHUNK = (KPT % 8 == 0) ? 8 : 4;
+#pragma unroll
+  for (int base = 0; base < KPT; base += CHUNK) {
+    uint32_t p[CHUNK];
+#pragma unroll
+    for (int c = 0; c < CHUNK; ++c) p[c] = waveBase[(key[base + c] >> shift) & 0xFFu];
+#pragma unroll
+    for (int c = 0; c < CHUNK; ++c) {
+      const int i = base + c;
+      uint32_t r;
+      if constexpr (PACKED)
+        r = (rank[i / 2] >> (16 * (i % 2))) & 0xFFFFu;
+      else
+        r = rank[i];
+      p[c] = StagingSlot<STAGE>(p[c] + r);
+      if (kAblate & (2u | 16u)) p[c] = (p[c] + i * 64) % STAGE;
+      sorted[p[c]] = key[i];
+      if constexpr (KEEP) {
+        if (c % 2 == 1) {
+          slots[i / 2] = p[c - 1] | (p[c] << 16);
+          asm volatile("" : "+v"(slots[i / 2]));  // pack now, not when first used
+        }
+      }
+    }
+  }
+}
+
+// The compiler would otherwise keep every key's LDS counter address (&waveHist[digit], computed for
+// the ranking) alive until the regroup: KPT more registers across the scan and the barriers.
+template <int KPT>
+__device__ __forceinline__ void ForgetDerivedValues(uint32_t (&key)[KPT]) {
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) asm volatile("" : "+v"(key[i]));
 }
 
 // Key+value tiles replay the permutation for the values through the SAME staging buffer after the
@@ -424,7 +505,7 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
 
   if (tid == 0) misc[0] = (kAblate & 8u) ? blockIdx.x : atomicAdd(a.ticketCur, 1u);
   for (int i = tid; i < WAVES * 256; i += THREADS) waveHist[i] = 0;
-  __syncthreads();
+  LdsBarrier();
   VRDX_STAMP(1);
 
   const uint32_t tile = misc[0];
@@ -471,7 +552,8 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
     RankAtomic<KPT, PACKED>(key, a.shift, waveHist + wave * 256, lane, rank);
   else
     RankBallot<KPT>(key, a.shift, waveHist + wave * 256, lane, rank);
-  __syncthreads();
+  ForgetDerivedValues<KPT>(key);
+  LdsBarrier();
   VRDX_STAMP(2);
 
   // ---- tile histogram, aggregate publish, tile-local digit offsets ---------------------------
@@ -499,26 +581,13 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
       run += c;
     }
   }
-  __syncthreads();
+  LdsBarrier();
   VRDX_STAMP(3);
 
   // ---- regroup the keys by digit in LDS; key+value keeps the positions for the values ----------
   uint32_t packedPos[KV ? KPT / 2 : 1];
-#pragma unroll
-  for (int i = 0; i < KPT; ++i) {
-    const uint32_t d = (key[i] >> a.shift) & 0xFFu;
-    const uint32_t r = PACKED ? ((rank[i / 2] >> (16 * (i % 2))) & 0xFFFFu) : rank[PACKED ? 0 : i];
-    uint32_t p = r + waveHist[wave * 256 + d];  // tile-local sorted position
-    if (kAblate & (2u | 16u)) p = (p + i * 64 + wave * KPT * 64) % TILE;
-    p = StagingSlot<TILE>(p);  // physical word; key+value remembers THIS for the values
-    sorted[p] = key[i];
-    if (KV) {
-      packedPos[i / 2] = (i % 2 == 0) ? p : (packedPos[i / 2] | (p << 16));
-      // pack NOW: left alone the compiler keeps all KPT positions unpacked until the value phase
-      if (i % 2 == 1) asm volatile("" : "+v"(packedPos[i / 2]));
-    }
-  }
-  __syncthreads();  // waveHist is dead from here on: the look-back reuses it as scratch
+  RegroupKeys<KPT, TILE, PACKED, KV>(key, rank, a.shift, waveHist + wave * 256, sorted, packedPos);
+  LdsBarrier();  // waveHist is dead from here on: the look-back reuses it as scratch
   VRDX_STAMP(4);
 
   // ---- decoupled look-back over the preceding tiles, then publish the inclusive prefix --------
@@ -531,7 +600,7 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
                   (VRDX_FLAG_INCLUSIVE << VRDX_FLAG_SHIFT) | ((exclusive + count) & VRDX_VALUE_MASK));
     tileOffset[tid] = exclusive - tileExclusive;
   }
-  __syncthreads();
+  LdsBarrier();
   VRDX_STAMP(5);
 
   // Key+value: fetch the values now; the key scatter covers their latency.  (Issued before the
@@ -582,10 +651,10 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
     }
   }
   if (KV) {
-    __syncthreads();  // every key has left the staging buffer
+    LdsBarrier();  // every key has left the staging buffer
 #pragma unroll
     for (int i = 0; i < KPT; ++i) sorted[(packedPos[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
-    __syncthreads();
+    LdsBarrier();
 #pragma unroll
     for (int j = 0; j < KPT / 4; ++j) {
       const uint32_t slot = 4u * (tid + j * THREADS);
@@ -603,6 +672,275 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
         }
       }
     }
+  }
+#ifdef VRDX_TRACE
+  VRDX_STAMP(6);
+  if (a.trace != nullptr && tid == 0) {
+    uint32_t xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    stamps[7] = ((uint64_t)(xcc & 0xF) << 60) | ((uint64_t)lookBackTrace << 24) | (blockIdx.x & 0xFFFFFFu);
+    for (int i = 0; i < 8; ++i) a.trace[(size_t)tile * 8 + i] = stamps[i];
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// onesweep_pair_kernel: one workgroup = TWO consecutive sub-tiles of THREADS*KPT keys, ONE status
+// row, ONE ticket and ONE look-back for both.
+// ---------------------------------------------------------------------------------------------
+// Why: the per-tile fixed costs (ticket 0.85 us, scan 0.9 us, look-back 3.1 us of a 16.5 us tile at
+// 1024x32, profiles/r01_phase_trace_1024x32_keys.txt) shrink only with the tile, and the tile is
+// capped by the LDS staging buffer (T words) and by the registers (KPT keys per lane).  Two
+// sub-tiles A and B go through the SAME staging buffer one after the other and hold registers for
+// one sub-tile's keys at a time, so the tile doubles at the same LDS and register footprint:
+//
+//   load A, rank A | issue the loads of B | scan A, regroup A into the staging buffer
+//   rank B, scan B | publish {AGGREGATE, countA + countB} | look-back (once)
+//   publish {INCLUSIVE, ...} | scatter A | regroup B | scatter B
+//
+// B's loads fly while A is scanned and regrouped.  Inside the tile A precedes B (B's digit base is
+// the tile's base + countA), so the result is the same stable permutation.
+//
+// LDS: staging (THREADS*KPT) | wave counters (WAVES*256) | look-back scratch + scan scratch +
+//      ticket | digit offsets of A and of B (2 x 256).
+template <int THREADS, int KPT>
+constexpr size_t PairLdsWords() {
+  return (size_t)THREADS * KPT + (size_t)(THREADS / 64) * 256 + (size_t)256 * (2 + 2 * (THREADS / 256)) + 512;
+}
+
+template <int THREADS, int KPT>
+constexpr int PairMinWavesPerSimd() {
+  constexpr int workgroups = (int)((160 * 1024) / (PairLdsWords<THREADS, KPT>() * 4));
+  constexpr int waves = workgroups * THREADS / 256;
+  return waves > 8 ? 8 : (waves < 1 ? 1 : waves);
+}
+
+// Quad scatter of one staged sub-tile (see onesweep_kernel's scatter stage).
+template <int THREADS, int KPT, bool KEEP_DIGITS>
+__device__ __forceinline__ void ScatterStagedKeys(const uint32_t* sorted, const uint32_t* offset, uint32_t* out,
+                                                  uint32_t valid, uint32_t shift, int tid,
+                                                  uint32_t (&digits)[KEEP_DIGITS ? KPT / 4 : 1]) {
+  constexpr uint32_t STAGE = THREADS * KPT;
+#pragma unroll
+  for (int j = 0; j < KPT / 4; ++j) {
+    const uint32_t slot = 4u * (tid + j * THREADS);
+    const uint32_t p = StagingSlot<STAGE>(slot);
+    const u32x4 k4 = *reinterpret_cast<const u32x4*>(&sorted[slot]);
+    const uint32_t d0 = (k4[0] >> shift) & 0xFFu, d1 = (k4[1] >> shift) & 0xFFu;
+    const uint32_t d2 = (k4[2] >> shift) & 0xFFu, d3 = (k4[3] >> shift) & 0xFFu;
+    if (p + 3 < valid && d0 == d3) {
+      *reinterpret_cast<u32x4_a4*>(out + offset[d0] + p) = k4;
+    } else {
+      const uint32_t dd[4] = {d0, d1, d2, d3};
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (p + c < valid) out[offset[dd[c]] + p + c] = k4[c];
+    }
+    if (KEEP_DIGITS) {
+      digits[j] = d0 | (d1 << 8) | (d2 << 16) | (d3 << 24);
+      if (j % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+template <int THREADS, int KPT>
+__device__ __forceinline__ void ScatterStagedValues(const uint32_t* sorted, const uint32_t* offset, uint32_t* out,
+                                                    uint32_t valid, int tid, const uint32_t (&digits)[KPT / 4]) {
+  constexpr uint32_t STAGE = THREADS * KPT;
+#pragma unroll
+  for (int j = 0; j < KPT / 4; ++j) {
+    const uint32_t slot = 4u * (tid + j * THREADS);
+    const uint32_t p = StagingSlot<STAGE>(slot);
+    const u32x4 v4 = *reinterpret_cast<const u32x4*>(&sorted[slot]);
+    const uint32_t d0 = digits[j] & 0xFFu, d3 = digits[j] >> 24;
+    if (p + 3 < valid && d0 == d3) {
+      *reinterpret_cast<u32x4_a4*>(out + offset[d0] + p) = v4;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t d = (digits[j] >> (8 * c)) & 0xFFu;
+        if (p + c < valid) out[offset[d] + p + c] = v4[c];
+      }
+    }
+  }
+}
+
+template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK>
+__global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) void onesweep_pair_kernel(OnesweepArgs a) {
+  constexpr int WAVES = THREADS / 64;
+  constexpr int GROUPS = THREADS / 256;
+  constexpr uint32_t SUB = THREADS * KPT;  // keys per sub-tile == staging buffer words
+  constexpr uint32_t TILE = 2 * SUB;
+  static_assert(THREADS >= 256 && THREADS % 256 == 0, "one thread per digit, whole look-back groups");
+  static_assert(KPT % 4 == 0, "quads");
+  static_assert(SUB <= 65536, "packed 16-bit positions");
+  static_assert(PairLdsWords<THREADS, KPT>() * 4 <= 160 * 1024, "fits the CU's LDS");
+
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  uint32_t* const sorted = smem;                                // SUB
+  uint32_t* const waveHist = smem + SUB;                        // WAVES x 256
+  uint32_t* const lookScratch = waveHist + WAVES * 256;         // 256 * (1 + 2 * GROUPS) + 2 used by LookBack
+  uint32_t* const scanScratch = lookScratch + 256 * (1 + 2 * GROUPS) + 8;  // 8
+  uint32_t* const misc = scanScratch + 8;                       // [0] ticket
+  uint32_t* const offsetA = lookScratch + 256 * (2 + 2 * GROUPS);  // 256: global base - local base, sub-tile A
+  uint32_t* const offsetB = offsetA + 256;                      // 256: same for sub-tile B
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+#ifdef VRDX_TRACE
+  uint64_t stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  VRDX_STAMP(0);
+
+  if (tid == 0) misc[0] = atomicAdd(a.ticketCur, 1u);
+  for (int i = tid; i < WAVES * 256; i += THREADS) waveHist[i] = 0;
+  LdsBarrier();
+  VRDX_STAMP(1);
+
+  const uint32_t tile = misc[0];
+  const uint32_t n = ElementCount(a.maxCount, a.countPtr);
+  const uint32_t tiles = (n + TILE - 1) / TILE;
+  if (tile >= tiles) return;  // uniform for the whole workgroup
+  const bool lastTile = tile == tiles - 1;
+  const uint32_t tileStart = tile * TILE;
+  const uint32_t left = n - tileStart;
+  const uint32_t validA = left < SUB ? left : SUB;
+  const uint32_t validB = left > SUB ? (left - SUB < SUB ? left - SUB : SUB) : 0u;
+
+  if (a.statusNext != nullptr) {
+    if (tid < 256 && tile < a.statusRows) a.statusNext[tile * VRDX_RADIX + tid] = 0;
+    if (tile == 0 && tid == 0) *a.ticketNext = 0;
+  }
+
+  constexpr bool PACKED = ATOMIC_RANK;  // ranks and positions < SUB <= 65536, two to a register
+  const uint32_t loadBaseA = tileStart + wave * (KPT * 64) + lane;
+  const uint32_t loadBaseB = loadBaseA + SUB;
+  uint32_t* const myHist = waveHist + wave * 256;
+
+  // ---- sub-tile A: load, rank ------------------------------------------------------------------
+  uint32_t keyA[KPT];
+  LoadStriped<KPT>(a.keysIn, loadBaseA, n, validA == SUB, 0xFFFFFFFFu, keyA);  // pad: downsweep.slang:81
+  uint32_t rankA[PACKED ? KPT / 2 : KPT];
+  if constexpr (ATOMIC_RANK)
+    RankAtomic<KPT, PACKED>(keyA, a.shift, myHist, lane, rankA);
+  else
+    RankBallot<KPT>(keyA, a.shift, myHist, lane, rankA);
+  ForgetDerivedValues<KPT>(keyA);
+
+  // ---- sub-tile B's keys start their trip now ---------------------------------------------------
+  __builtin_amdgcn_sched_barrier(0);  // not earlier: A's keys and ranks are live
+  uint32_t keyB[KPT];
+  LoadStriped<KPT>(a.keysIn, loadBaseB, n, validB == SUB, 0xFFFFFFFFu, keyB);
+  LdsBarrier();
+  VRDX_STAMP(2);
+
+  // ---- A: tile histogram -> local digit offsets -------------------------------------------------
+  uint32_t countA = 0;
+  if (tid < 256) {
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) countA += waveHist[w * 256 + tid];
+  }
+  const uint32_t localA = BlockExclusiveScan256(tid < 256 ? countA : 0u, scanScratch, tid);
+  uint32_t exclusive = 0;
+  if (tile == 0) {
+    // spine.slang:62-83 equivalent: exclusive scan of this pass's 256 global digit counts.
+    const uint32_t g = tid < 256 ? a.globalHistogram[tid] : 0u;
+    exclusive = BlockExclusiveScan256(g, scanScratch + 4, tid);
+  }
+  if (tid < 256) {
+    uint32_t run = localA;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+      const uint32_t c = waveHist[w * 256 + tid];
+      waveHist[w * 256 + tid] = run;
+      run += c;
+    }
+  }
+  LdsBarrier();
+
+  // ---- A: regroup into the staging buffer; from here to the next barrier a wave only touches ITS
+  // row of the counters, so it can clear the row and rank B without waiting for the others -------
+  uint32_t packedPosA[KV ? KPT / 2 : 1];
+  RegroupKeys<KPT, SUB, PACKED, KV>(keyA, rankA, a.shift, myHist, sorted, packedPosA);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) myHist[lane + 64 * i] = 0;
+
+  uint32_t rankB[PACKED ? KPT / 2 : KPT];
+  if constexpr (ATOMIC_RANK)
+    RankAtomic<KPT, PACKED>(keyB, a.shift, myHist, lane, rankB);
+  else
+    RankBallot<KPT>(keyB, a.shift, myHist, lane, rankB);
+  ForgetDerivedValues<KPT>(keyB);
+  LdsBarrier();
+  VRDX_STAMP(3);
+
+  // ---- B: tile histogram; publish the tile's aggregate; local digit offsets ---------------------
+  uint32_t countB = 0;
+  if (tid < 256) {
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) countB += waveHist[w * 256 + tid];
+    if (tile != 0 && !lastTile)
+      StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid],
+                  (VRDX_FLAG_AGGREGATE << VRDX_FLAG_SHIFT) | (countA + countB));
+  }
+  const uint32_t localB = BlockExclusiveScan256(tid < 256 ? countB : 0u, scanScratch, tid);
+  if (tid < 256) {
+    uint32_t run = localB;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+      const uint32_t c = waveHist[w * 256 + tid];
+      waveHist[w * 256 + tid] = run;
+      run += c;
+    }
+  }
+  LdsBarrier();
+  VRDX_STAMP(4);
+
+  // ---- one look-back for both sub-tiles ----------------------------------------------------------
+  uint32_t lookBackTrace = 0;
+  if (tile != 0) exclusive = LookBack<THREADS>(a.statusCur, tile, tid, lookScratch, a.failure, &lookBackTrace);
+  if (tid < 256) {
+    if (!lastTile)
+      StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid],
+                  (VRDX_FLAG_INCLUSIVE << VRDX_FLAG_SHIFT) | ((exclusive + countA + countB) & VRDX_VALUE_MASK));
+    offsetA[tid] = exclusive - localA;
+    offsetB[tid] = exclusive + countA - localB;
+  }
+  LdsBarrier();
+  VRDX_STAMP(5);
+
+  // ---- scatter A ---------------------------------------------------------------------------------
+  uint32_t digits[KV ? KPT / 4 : 1];
+  if constexpr (KV) {
+    uint32_t val[KPT];
+    LoadStriped<KPT>(a.valuesIn, loadBaseA, n, validA == SUB, 0u, val);  // pad: downsweep.slang:85
+    ScatterStagedKeys<THREADS, KPT, true>(sorted, offsetA, a.keysOut, validA, a.shift, tid, digits);
+    LdsBarrier();
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) sorted[(packedPosA[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
+    LdsBarrier();
+    ScatterStagedValues<THREADS, KPT>(sorted, offsetA, a.valuesOut, validA, tid, digits);
+  } else {
+    ScatterStagedKeys<THREADS, KPT, false>(sorted, offsetA, a.keysOut, validA, a.shift, tid, digits);
+  }
+  LdsBarrier();  // the staging buffer is free again
+
+  // ---- B: regroup, scatter -----------------------------------------------------------------------
+  uint32_t packedPosB[KV ? KPT / 2 : 1];
+  RegroupKeys<KPT, SUB, PACKED, KV>(keyB, rankB, a.shift, myHist, sorted, packedPosB);
+  LdsBarrier();
+  if constexpr (KV) {
+    uint32_t val[KPT];
+    LoadStriped<KPT>(a.valuesIn, loadBaseB, n, validB == SUB, 0u, val);
+    ScatterStagedKeys<THREADS, KPT, true>(sorted, offsetB, a.keysOut, validB, a.shift, tid, digits);
+    LdsBarrier();
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) sorted[(packedPosB[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
+    LdsBarrier();
+    ScatterStagedValues<THREADS, KPT>(sorted, offsetB, a.valuesOut, validB, tid, digits);
+  } else {
+    ScatterStagedKeys<THREADS, KPT, false>(sorted, offsetB, a.keysOut, validB, a.shift, tid, digits);
   }
 #ifdef VRDX_TRACE
   VRDX_STAMP(6);
@@ -690,8 +1028,42 @@ static void LaunchConfig(hipStream_t stream, uint32_t grid, bool keyValue, bool 
   }
 }
 
+template <int THREADS, int KPT>
+static hipError_t PreparePairConfig() {
+  const int bytes = (int)(PairLdsWords<THREADS, KPT>() * sizeof(uint32_t));
+  const void* kernels[4] = {
+      reinterpret_cast<const void*>(&onesweep_pair_kernel<THREADS, KPT, false, false>),
+      reinterpret_cast<const void*>(&onesweep_pair_kernel<THREADS, KPT, false, true>),
+      reinterpret_cast<const void*>(&onesweep_pair_kernel<THREADS, KPT, true, false>),
+      reinterpret_cast<const void*>(&onesweep_pair_kernel<THREADS, KPT, true, true>),
+  };
+  for (const void* fn : kernels) {
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+template <int THREADS, int KPT>
+static void LaunchPairConfig(hipStream_t stream, uint32_t grid, bool keyValue, bool atomicRank,
+                             const OnesweepArgs& args) {
+  const size_t lds = PairLdsWords<THREADS, KPT>() * sizeof(uint32_t);
+  const dim3 g(grid), b(THREADS);
+  if (keyValue) {
+    if (atomicRank)
+      hipLaunchKernelGGL((onesweep_pair_kernel<THREADS, KPT, true, true>), g, b, lds, stream, args);
+    else
+      hipLaunchKernelGGL((onesweep_pair_kernel<THREADS, KPT, true, false>), g, b, lds, stream, args);
+  } else {
+    if (atomicRank)
+      hipLaunchKernelGGL((onesweep_pair_kernel<THREADS, KPT, false, true>), g, b, lds, stream, args);
+    else
+      hipLaunchKernelGGL((onesweep_pair_kernel<THREADS, KPT, false, false>), g, b, lds, stream, args);
+  }
+}
+
 const TileConfig kTileConfigs[kNumTileConfigs] = {
-    {512, 16}, {1024, 16}, {512, 32}, {1024, 8}, {512, 24}, {512, 28}, {512, 20}, {1024, 32},
+    {512, 16, 1}, {1024, 16, 1}, {512, 32, 1}, {1024, 8, 1}, {512, 24, 1}, {512, 28, 1}, {512, 20, 1}, {1024, 32, 1}, {1024, 32, 2}, {512, 32, 2},
 };
 
 hipError_t PrepareKernels(int configIndex) {
@@ -704,6 +1076,8 @@ hipError_t PrepareKernels(int configIndex) {
     case 5: return PrepareConfig<512, 28>();
     case 6: return PrepareConfig<512, 20>();
     case 7: return PrepareConfig<1024, 32>();
+    case 8: return PreparePairConfig<1024, 32>();
+    case 9: return PreparePairConfig<512, 32>();
     default: return hipErrorInvalidValue;
   }
 }
@@ -740,6 +1114,8 @@ void LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool key
     case 5: LaunchConfig<512, 28>(stream, grid, keyValue, atomicRank, args); break;
     case 6: LaunchConfig<512, 20>(stream, grid, keyValue, atomicRank, args); break;
     case 7: LaunchConfig<1024, 32>(stream, grid, keyValue, atomicRank, args); break;
+    case 8: LaunchPairConfig<1024, 32>(stream, grid, keyValue, atomicRank, args); break;
+    case 9: LaunchPairConfig<512, 32>(stream, grid, keyValue, atomicRank, args); break;
     default: break;
   }
 }
