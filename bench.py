@@ -162,6 +162,18 @@ def cpu_baseline(n):
     }
 
 
+def kernel_name(version, which):
+    """Dominant kernel of the sort at the bench size, from the library's own description of its tile
+    choice ("... keys=1024x32x2 key-value=1024x32 ..."): AxB -> onesweep_kernel<A, B, ...>,
+    AxBx2 -> onesweep_pair_kernel<A, B, ...> (two sub-tiles per workgroup)."""
+    import re
+    m = re.search(which + r"=(\d+)x(\d+)(x2)?", version)
+    if not m:
+        return "onesweep_kernel"
+    kv = "true" if which == "key-value" else "false"
+    return "%s<%s, %s, %s, true>" % ("onesweep_pair_kernel" if m.group(3) else "onesweep_kernel", m.group(1), m.group(2), kv)
+
+
 def latest_pmc_traffic():
     """HBM bytes per onesweep launch from the rocprofv3 PMC passes committed under profiles/
     (collected offline: PMC cannot be read from inside this process)."""
@@ -216,8 +228,9 @@ def main():
     sweep_bytes = 8.0 * n
     achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
     pmc = latest_pmc_traffic()
+    version = vrdx.version_string()
     roofline = {
-        "bound": "hbm", "kernel": "onesweep_kernel<keys-only>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+        "bound": "hbm", "kernel": kernel_name(version, "keys"), "achieved": achieved, "peak": HBM_PEAK_GBPS,
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
         "traffic": (pmc or {}).get("onesweep_keys_bytes_per_launch"),
         "algorithmic_bytes_per_launch": sweep_bytes, "avg_launch_ms": sweep_ms,
@@ -226,7 +239,7 @@ def main():
         "whole_sort": {"algorithmic_bytes": KEYS_BYTES_PER_ITEM * n,
                        "achieved": KEYS_BYTES_PER_ITEM * n / (med_keys_ms * 1e-3) / 1e9,
                        "frac": KEYS_BYTES_PER_ITEM * n / (med_keys_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
-        "key_value": {"kernel": "onesweep_kernel<key-value>", "avg_launch_ms": sweep_kv_ms,
+        "key_value": {"kernel": kernel_name(version, "key-value"), "avg_launch_ms": sweep_kv_ms,
                       "achieved": 16.0 * n / (sweep_kv_ms * 1e-3) / 1e9,
                       "frac": 16.0 * n / (sweep_kv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                       "whole_sort_achieved": KV_BYTES_PER_ITEM * n / (med_kv_ms * 1e-3) / 1e9,
@@ -242,7 +255,7 @@ def main():
                                f"(BASELINE.json configs[1]); key+value (configs[2]) under key_value",
                    "n": n, "arrays_per_step_per_gpu": 1,
                    "parallelism": "independent arrays, one per GPU, no data-path collective" if distributed else "single GPU",
-                   "tile": vrdx.version_string()},
+                   "tile": version},
         "median_gpu_ms_per_sort": med_keys_ms, "median_gitems_per_s": n / (med_keys_ms * 1e-3) / 1e9,
         "key_value": {"value": value_kv, "unit": "GItems/s", "ms_per_step": wall_kv / args.steps * 1e3,
                       "median_gpu_ms_per_sort": med_kv_ms, "median_gitems_per_s": n / (med_kv_ms * 1e-3) / 1e9},

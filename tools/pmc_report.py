@@ -43,7 +43,9 @@ def main():
     for name in fetch:
         if "onesweep" in name:
             rd, wr = fetch[name] * f4, write.get(name, 0.0) * w4
-            kind = "key_value" if ", true, " in name.split("onesweep_kernel")[1][:24] else "keys"
+            # onesweep_kernel<THREADS, KPT, KV, ATOMIC_RANK> / onesweep_pair_kernel<...>: third argument
+            targs = [t.strip() for t in name.split("<", 1)[1].split(">", 1)[0].split(",")]
+            kind = "key_value" if targs[2] == "true" else "keys"
         elif "histogram" in name:
             rd, wr = fetch[name] * f16, write.get(name, 0.0) * w4
             kind = "histogram"
