@@ -85,7 +85,7 @@ int ConfigIndex(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount
   const double f = (double)elementCount / ((double)sorter->computeUnits * 32768.0);
   const double intoRound = f - std::floor(f);  // 0 = exactly full rounds
   if (keyValue) {
-    if (f <= 0.25) return kCfg1024x8;
+    if (f <= 0.26) return kCfg1024x8;
     if (f <= 0.53) return kCfg1024x16;
     if (f <= 1.0) return kCfg1024x32;
     if (f <= 4.0 && intoRound > 0.0 && intoRound <= 0.45) return kCfg1024x16;
@@ -234,6 +234,12 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   }
 
   const uint32_t tiles = vrdx::RoundUp(elementCount, tileKeys);
+  // Key+value tiles fetch their values early (right after the ranking) or late (after the look-back),
+  // whichever measured faster (vrdx_selftest sweep, profiles/r01_sweep_kv_early_values.txt): early
+  // wins by 3-11 % for every geometry up to about three rounds of 32768-key tiles per CU, late by
+  // 1-3 % beyond.
+  bool earlyValues = (double)elementCount <= 3.1 * 32768.0 * (double)sorter->computeUnits;
+  if (const char* env = std::getenv("VRDX_KV_EARLY_VALUES")) earlyValues = env[0] == '1';  // tuning/testing
   for (uint32_t pass = 0; pass < VRDX_PASSES; ++pass) {
     Stamp(pool, query + 2 + 3 * pass + 0, stream);  // "upsweep" of this pass
     Stamp(pool, query + 2 + 3 * pass + 1, stream);  // "spine" (fused into the onesweep look-back)
@@ -256,6 +262,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     args.ticketNext = tickets + ((pass + 1) & 1u);
     args.failure = failure;
     args.shift = 8 * pass;
+    args.earlyValues = earlyValues ? 1u : 0u;
     args.trace = nullptr;
 #ifdef VRDX_TRACE
     args.trace = TraceBuffer(pass, tiles);

@@ -47,6 +47,7 @@ struct OnesweepArgs {
   uint32_t* ticketNext;
   uint32_t* failure;
   uint32_t shift;             // 8 * pass
+  uint32_t earlyValues;       // KV: fetch the values right after the ranking instead of after the look-back
   unsigned long long* trace;  // phase stamps, 8 per tile; nullptr outside tools/trace.sh builds
 };
 

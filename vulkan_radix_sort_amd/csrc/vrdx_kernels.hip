@@ -35,6 +35,7 @@ namespace vrdx {
 #endif
 constexpr uint32_t kAblate = VRDX_ABLATE;
 
+
 // Timing-only phase trace for tools/trace.sh (never defined in the product build): thread 0 of
 // every tile stores 100 MHz wall-clock stamps of its phase boundaries into OnesweepArgs::trace.
 #ifdef VRDX_TRACE
@@ -526,20 +527,12 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   // ---- load: wave-striped, so that (slot, lane) order == memory order inside a wave ----------
   // (the values are fetched once the keys have been staged)
   uint32_t key[KPT];
+  uint32_t val[KV ? KPT : 1];
   const uint32_t loadBase = tileStart + wave * (KPT * 64) + lane;
-  if (valid == TILE) {
-#pragma unroll
-    for (int i = 0; i < KPT; ++i) key[i] = a.keysIn[loadBase + i * 64];
-  } else {
-    // Ragged last tile: pad with 0xFFFFFFFF like the reference (downsweep.slang:81).  Pads sit
-    // at the highest memory positions of the tile and have digit 255 in every pass, so the
-    // stable ranking puts them at tile-local positions >= valid, where nothing is written.
-#pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-      const uint32_t idx = loadBase + i * 64;
-      key[i] = idx < n ? a.keysIn[idx] : 0xFFFFFFFFu;
-    }
-  }
+  // Ragged last tile: pad with 0xFFFFFFFF like the reference (downsweep.slang:81).  Pads sit at the
+  // highest memory positions of the tile and have digit 255 in every pass, so the stable ranking
+  // puts them at tile-local positions >= valid, where nothing is written.
+  LoadStriped<KPT>(a.keysIn, loadBase, n, valid == TILE, 0xFFFFFFFFu, key);
 
   // ---- rank inside the wave (memory order) ---------------------------------------------------
   // key+value: ranks / positions live until the values are staged, so they are kept packed two to
@@ -553,6 +546,10 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   else
     RankBallot<KPT>(key, a.shift, waveHist + wave * 256, lane, rank);
   ForgetDerivedValues<KPT>(key);
+  // key+value, early form: the values start their trip now and land during the scan and the regroup
+  if constexpr (KV) {
+    if (a.earlyValues) LoadStriped<KPT>(a.valuesIn, loadBase, n, valid == TILE, 0u, val);  // pad: downsweep.slang:85
+  }
   LdsBarrier();
   VRDX_STAMP(2);
 
@@ -603,23 +600,14 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   LdsBarrier();
   VRDX_STAMP(5);
 
-  // Key+value: fetch the values now; the key scatter covers their latency.  (Issued before the
-  // look-back they sit in this CU's memory queue in front of its agent-scope status reads and
-  // stretch the look-back from 6 to 9 us -- measured.)
-  uint32_t val[KV ? KPT : 1];
-  if (KV) {
-    if (valid == TILE) {
-#pragma unroll
-      for (int i = 0; i < KPT; ++i) val[i] = a.valuesIn[loadBase + i * 64];
-    } else {
-#pragma unroll
-      for (int i = 0; i < KPT; ++i) {
-        const uint32_t idx = loadBase + i * 64;
-        val[i] = idx < n ? a.valuesIn[idx] : 0u;  // downsweep.slang:85
-      }
-    }
+  // Key+value, late form: the values are fetched now and the key scatter covers their latency.
+  // The host picks the form per sort from measurements (RecordSort): early wins by 3-11 % up to about
+  // three rounds of tiles per CU (1024x32 at 2^24 pairs: 0.278 vs 0.311 ms), late by 1-3 % beyond
+  // (2^25: 0.574 vs 0.590 ms).  Issued right before the look-back the loads queue in front of its
+  // agent-scope status reads (6 -> 9 us, measured).
+  if constexpr (KV) {
+    if (!a.earlyValues) LoadStriped<KPT>(a.valuesIn, loadBase, n, valid == TILE, 0u, val);
   }
-
 
   // ---- scatter: four consecutive sorted positions per lane ------------------------------------
   // The staging buffer is sorted by digit, so the four keys of a quad almost always share their
