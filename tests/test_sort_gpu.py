@@ -387,6 +387,50 @@ def test_large_ragged_2pow28_properties(torch_mod, sorter):
     del u, xor_before
 
 
+def test_maximum_size_2pow30_minus_4_properties(torch_mod, sorter):
+    """The largest count the interface admits: N = 2^30 - 4 keys.  The reference sizes its buffers in
+    uint32 arithmetic (src/vk_radix_sort.h.in:105-115): Align(4 * N, 16) = (4N + 15) / 16 * 16 wraps
+    from N = 2^30 - 3 on, and the storage requirement (which we reproduce bit for bit) collapses.
+    4 GiB of keys + 4 GiB of storage; size-independent properties only, computed on the GPU in
+    chunks: sortedness, multiset checksums (sum and sum of squares mod 2^64), failure word."""
+    torch = torch_mod
+    n = (1 << 30) - 4
+    free, _ = torch.cuda.mem_get_info()
+    if free < 24 * (1 << 30):
+        pytest.skip("needs 24 GiB of free HBM")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    keys = torch.empty(n, dtype=torch.int32, device="cuda")
+    chunk = 1 << 27
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        keys[lo:hi] = torch.randint(-(1 << 31), 1 << 31, (hi - lo,), generator=g, device="cuda",
+                                    dtype=torch.int64).to(torch.int32)
+
+    def checksums(t):
+        s1 = s2 = 0
+        for lo in range(0, n, chunk):
+            u = t[lo:min(n, lo + chunk)].to(torch.int64) & 0xFFFFFFFF
+            s1 = (s1 + int(u.sum().item())) & ((1 << 64) - 1)
+            s2 = (s2 + int((u * u).sum().item())) & ((1 << 64) - 1)   # wraps mod 2^64 like int64 does
+        return s1, s2
+
+    before = checksums(keys)
+    req = sorter.storage_requirements(n)
+    assert req.size >= 4 * n
+    storage = torch.empty(req.size, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    sorter.cmd_sort(stream, n, keys.data_ptr(), 0, storage.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert sorter.read_status(stream, storage.data_ptr(), 0) == 0
+    del storage
+    assert checksums(keys) == before
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk + 1)          # overlap by one element: boundaries are checked too
+        u = keys[lo:hi].to(torch.int64) & 0xFFFFFFFF
+        assert bool((u[1:] >= u[:-1]).all()), lo
+
+
 def test_native_selftest_binary(torch_mod):
     """The same battery from plain C++ (no torch in the process): tests/native/vrdx_selftest."""
     exe = os.path.join(ROOT, "tests", "native", "vrdx_selftest")

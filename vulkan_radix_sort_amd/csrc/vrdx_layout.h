@@ -19,7 +19,7 @@
 // up to itself (flag INCLUSIVE).  The last tile is never looked at, so rows = tiles - 1, and two
 // regions (pass p uses region p & 1 and zeroes its own row of the other one for pass p + 1) need
 // 2 * (ceil(N/TILE) - 1) KiB <= P KiB, which holds for every N when TILE >= 8192.
-// N < 2^30 (the reference's uint32 byte-size math has the same ceiling, :106,113-115) keeps every
+// N <= 2^30 - 4 (the reference's uint32 byte-size math wraps above that, :105-115) keeps every
 // prefix inside 30 bits.
 #ifndef VRDX_LAYOUT_H
 #define VRDX_LAYOUT_H
@@ -37,7 +37,7 @@
 #define VRDX_FLAG_AGGREGATE 1u
 #define VRDX_FLAG_INCLUSIVE 2u
 
-#define VRDX_MAX_ELEMENTS 0x3FFFFFFFu /* N < 2^30 */
+#define VRDX_MAX_ELEMENTS 0x3FFFFFFCu /* 2^30 - 4: beyond it the reference's uint32 Align(4 * N, 16) wraps (:105-115) */
 
 /* offsets inside the first 16 bytes */
 #define VRDX_OFF_COUNT 0u
