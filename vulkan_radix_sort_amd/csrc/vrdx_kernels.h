@@ -15,7 +15,7 @@ namespace vrdx {
 #define VRDX_HIST_COPIES 8
 #endif
 #ifndef VRDX_HIST_WGS_PER_CU
-#define VRDX_HIST_WGS_PER_CU 2
+#define VRDX_HIST_WGS_PER_CU 1
 #endif
 constexpr uint32_t kHistThreads = VRDX_HIST_THREADS;
 constexpr uint32_t kHistCopies = VRDX_HIST_COPIES;
