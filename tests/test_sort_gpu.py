@@ -169,6 +169,18 @@ def test_indirect_count_and_untouched_tail(torch_mod, sorter, oracle, kv):
     assert np.array_equal(gk, ek) and (not kv or np.array_equal(gv, ev))
 
 
+@pytest.mark.parametrize("kv", [False, True])
+def test_indirect_count_with_large_bound(torch_mod, sorter, oracle, kv):
+    """Indirect sorts whose host-side bound selects the big-tile kernels (12 M: the two-sub-tile kernel
+    for keys-only, 32768-key tiles for key+value) while the device-side count is anything from 0 to the
+    bound: workgroups beyond the real tile count leave at once, the tail is untouched."""
+    bound = 12_000_017
+    k, v = oracle.generate(13, bound, 32)
+    for count in (0, 1, 65_537, 9_000_001, bound):
+        check_against_oracle(torch_mod, sorter, oracle, k, v if kv else None, count=count, indirect=True,
+                             max_count=bound)
+
+
 def test_buffer_offsets_and_shared_buffer(torch_mod, sorter, oracle):
     # keys, values and the count in ONE buffer at different offsets, exactly like the reference's
     # only KV call site (bench/vulkan_benchmark.cc:346-358,386-388)
