@@ -17,6 +17,9 @@
 //     look-back over the preceding tiles (agent-scope relaxed atomics: the 8 XCD L2s are not
 //     coherent), regroups keys by digit in LDS and writes them out four at a time with consecutive
 //     lanes on consecutive addresses; values replay the permutation through the same LDS buffer.
+//   * onesweep_pair_kernel -- the same pass with TWO 32768-key sub-tiles per workgroup, one ticket,
+//     one status row and one look-back for both (keys-only sorts of one to two and of four "rounds"
+//     of tiles per CU, see ConfigIndex in vrdx_api.cpp).
 //   Tile ids are handed out by an atomic ticket in ARRIVAL order, so a look-back only ever waits
 //   on a tile that is already running; every spin is bounded (failure word, never a hang).
 #include <hip/hip_runtime.h>
@@ -611,7 +614,7 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
 
   // ---- scatter: four consecutive sorted positions per lane ------------------------------------
   // The staging buffer is sorted by digit, so the four keys of a quad almost always share their
-  // digit (runs are ~64 keys on uniform data) and go to four consecutive words: one 16-byte LDS read
+  // digit (runs are 64-128 keys on uniform data) and go to four consecutive words: one 16-byte LDS read
   // and one 16-byte store (4-byte aligned: gfx950 global stores need no natural alignment) instead of
   // four of each; consecutive lanes still cover consecutive addresses.  A quad that straddles a run
   // boundary or the ragged end falls back to single stores.
