@@ -20,6 +20,9 @@ namespace vrdx {
 constexpr uint32_t kHistThreads = VRDX_HIST_THREADS;
 constexpr uint32_t kHistCopies = VRDX_HIST_COPIES;
 constexpr uint32_t kHistWorkgroupsPerCu = VRDX_HIST_WGS_PER_CU;
+constexpr uint32_t kHistCopiesLarge = 32;          // sorts of kHistManyCopiesFrom keys and more
+constexpr uint32_t kHistManyCopiesFrom = 1u << 24;
+constexpr uint32_t HistLdsBytes(uint32_t copies) { return 4u * 256u * copies * 4u; }  // [pass][digit][copy]
 // keys one histogram workgroup handles per loop trip (kHistThreads lanes x 4 uint4 x 4 keys)
 constexpr uint32_t kHistKeysPerTrip = kHistThreads * 4 * 4;
 

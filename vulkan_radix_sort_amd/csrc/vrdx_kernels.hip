@@ -149,27 +149,34 @@ __device__ __forceinline__ uint32_t BlockExclusiveScan256(uint32_t v, uint32_t* 
 // ---------------------------------------------------------------------------------------------
 // histogram: all four digit histograms in one pass over the keys
 // ---------------------------------------------------------------------------------------------
-// LDS counters are replicated HIST_COPIES times (copy = lane % HIST_COPIES, copies of one bin in
-// consecutive banks) so that all-equal / few-distinct keys do not serialise on one LDS address
-// the way the reference's 512-way atomicAdd on localHistogram[radix] does (upsweep.slang:34).
+// LDS counters are replicated COPIES times (copy = lane % COPIES, copies of one bin in consecutive
+// banks) so that all-equal / few-distinct keys do not serialise on one LDS address the way the
+// reference's 512-way atomicAdd on localHistogram[radix] does (upsweep.slang:34).  With 32 copies
+// (128 KiB, one workgroup per CU) two lanes of a wave can only meet in a bank if they are 32 apart,
+// so every ds_add takes at most two passes whatever the keys are: constant, sorted and few-distinct
+// inputs sort 6-8 % faster at N = 2^25 than with 8 copies (uniform keys: no difference, the kernel
+// is not LDS-bound there).  Clearing and reducing 128 KiB costs ~3 us, so sorts below 2^24 keys use
+// 8 copies (32 KiB).
 
+template <uint32_t COPIES>
 __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t* __restrict__ keys,
                                                                   uint32_t maxCount,
                                                                   const uint32_t* countPtr,
                                                                   uint32_t* __restrict__ globalHistogram) {
-  __shared__ uint32_t bins[VRDX_PASSES * VRDX_RADIX * kHistCopies];
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  uint32_t* const bins = smem;  // [pass][digit][copy]
   const uint32_t tid = threadIdx.x;
   const uint32_t n = ElementCount(maxCount, countPtr);
 
-  for (uint32_t i = tid; i < VRDX_PASSES * VRDX_RADIX * kHistCopies; i += kHistThreads) bins[i] = 0;
+  for (uint32_t i = tid; i < VRDX_PASSES * VRDX_RADIX * COPIES; i += kHistThreads) bins[i] = 0;
   __syncthreads();
 
-  const uint32_t copy = tid & (kHistCopies - 1);
+  const uint32_t copy = tid & (COPIES - 1);
   auto count = [&](uint32_t key) {
 #pragma unroll
     for (uint32_t p = 0; p < VRDX_PASSES; ++p) {
       const uint32_t d = (key >> (8 * p)) & 0xFFu;
-      atomicAdd(&bins[(p * VRDX_RADIX + d) * kHistCopies + copy], 1u);
+      atomicAdd(&bins[(p * VRDX_RADIX + d) * COPIES + copy], 1u);
     }
   };
 
@@ -200,8 +207,9 @@ __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t*
 
   for (uint32_t b = tid; b < VRDX_PASSES * VRDX_RADIX; b += kHistThreads) {
     uint32_t sum = 0;
+    // rotated by the lane so that the lanes of one read do not all hit copy c's bank
 #pragma unroll
-    for (uint32_t c = 0; c < kHistCopies; ++c) sum += bins[b * kHistCopies + c];
+    for (uint32_t c = 0; c < COPIES; ++c) sum += bins[b * COPIES + ((c + tid) & (COPIES - 1))];
     if (sum != 0) atomicAdd(&globalHistogram[b], sum);
   }
 }
@@ -1058,6 +1066,14 @@ const TileConfig kTileConfigs[kNumTileConfigs] = {
 };
 
 hipError_t PrepareKernels(int configIndex) {
+  if (configIndex == 0) {  // once per sorter: the histogram kernel's dynamic LDS
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&histogram_kernel<kHistCopies>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)HistLdsBytes(kHistCopies));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&histogram_kernel<kHistCopiesLarge>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)HistLdsBytes(kHistCopiesLarge));
+    if (e != hipSuccess) return e;
+  }
   switch (configIndex) {
     case 0: return PrepareConfig<512, 16>();
     case 1: return PrepareConfig<1024, 16>();
@@ -1090,8 +1106,12 @@ hipError_t LdsOrderCheck(bool* laneOrdered) {
 
 void LaunchHistogram(hipStream_t stream, uint32_t grid, const uint32_t* keys, uint32_t maxCount,
                      const uint32_t* countPtr, uint32_t* globalHistogram) {
-  hipLaunchKernelGGL(histogram_kernel, dim3(grid), dim3(kHistThreads), 0, stream, keys, maxCount, countPtr,
-                     globalHistogram);
+  if (maxCount >= kHistManyCopiesFrom)
+    hipLaunchKernelGGL(histogram_kernel<kHistCopiesLarge>, dim3(grid), dim3(kHistThreads),
+                       HistLdsBytes(kHistCopiesLarge), stream, keys, maxCount, countPtr, globalHistogram);
+  else
+    hipLaunchKernelGGL(histogram_kernel<kHistCopies>, dim3(grid), dim3(kHistThreads), HistLdsBytes(kHistCopies),
+                       stream, keys, maxCount, countPtr, globalHistogram);
 }
 
 void LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool keyValue, bool atomicRank,
