@@ -33,6 +33,7 @@ namespace vrdx {
 // Timing-only ablation switches for tools/ablate.sh (results are WRONG when any bit is set; the
 // product build always has VRDX_ABLATE == 0):  1 no look-back   2 no match ranking
 // 4 linear instead of scattered stores   8 tile = blockIdx (no ticket)   16 no wave counters
+// 32 every quad takes the 16-byte store path
 #ifndef VRDX_ABLATE
 #define VRDX_ABLATE 0
 #endif
@@ -465,6 +466,124 @@ __device__ __forceinline__ void ForgetDerivedValues(uint32_t (&key)[KPT]) {
   for (int i = 0; i < KPT; ++i) asm volatile("" : "+v"(key[i]));
 }
 
+// ---- scatter of a staged (sub-)tile: four consecutive sorted positions per lane ---------------
+// The staging buffer is sorted by digit, so the four keys of a quad almost always share their digit
+// (runs are 64-128 keys on uniform data) and go to four consecutive words: one 16-byte LDS read and
+// one 16-byte store (4-byte aligned: gfx950 global stores need no natural alignment) instead of four
+// of each; consecutive lanes still cover consecutive addresses.
+//
+// A quad that straddles a run boundary is rare per lane, but SOME lane of almost every wave has one
+// (87 % of the wave-level quads at 128-key runs), and a wave walks through every branch any of its
+// lanes takes: handled inside the main loop, word-by-word stores cost the pass 6-7 % (measured with
+// the timing ablation 32).  So the main loop only stores whole single-digit quads, and the
+// straddling quads are done afterwards by the threads that know where they are: thread d (< 256)
+// holds the tile-local start of digit d's run from the scan; if that start is not a multiple of
+// four, the quad around it straddles, and every straddling quad inside the valid range contains the
+// start of some non-empty run.  Thread 0 (digit 0 starts at 0) takes the quad cut by a ragged end.
+// Two runs shorter than four keys can put the same quad on two threads: the same words go to the same
+// addresses twice.
+__device__ __forceinline__ void StoreWord(uint32_t* base, uint32_t index, uint32_t value) {
+  // 32-bit byte offset (N < 2^30) on a 64-bit base: one address register instead of a 64-bit pair
+  *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(base) + (uint64_t)(index * 4u)) = value;
+}
+
+// Tile-local position of the straddling quad this thread is responsible for, or ~0u.
+__device__ __forceinline__ uint32_t BoundaryQuad(int tid, uint32_t myRunStart, uint32_t myRunLength, uint32_t valid) {
+  uint32_t quad = ~0u;
+  if (tid < 256 && myRunLength != 0 && (myRunStart & 3u) != 0 && myRunStart < valid) quad = myRunStart & ~3u;
+  if (tid == 0 && (valid & 3u) != 0) quad = valid & ~3u;
+  return quad;
+}
+
+template <uint32_t STAGE>
+__device__ __forceinline__ void StoreBoundaryQuad(const uint32_t* sorted, const uint32_t* offset, uint32_t* out,
+                                                  uint32_t quad, uint32_t valid, uint32_t packedDigits,
+                                                  uint32_t linearBase) {
+  const u32x4 q = *reinterpret_cast<const u32x4*>(&sorted[StagingSlot<STAGE>(quad)]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const uint32_t d = (packedDigits >> (8 * c)) & 0xFFu;
+    if (quad + c < valid) StoreWord(out, ((kAblate & 4u) ? linearBase : offset[d]) + quad + c, q[c]);
+  }
+}
+
+// KEEP_DIGITS (key+value): digits[j] = first | last << 8 digit of main-loop quad j, and
+// boundaryDigits = the four digits of this thread's boundary quad, for the value phase.
+// Quads per batch: the 16-byte LDS reads of a batch are issued together, then its offset lookups,
+// then its stores -- left alone the compiler does one quad at a time, two dependent LDS round trips
+// each, with only four waves per SIMD to hide them.
+template <int KPT, bool KV>
+constexpr int ScatterBatch() {
+  constexpr int quads = KPT / 4;
+  constexpr int want = KV ? 4 : 8;  // key+value: the values and their slots are live as well
+  return quads % want == 0 ? want : (quads % 4 == 0 ? 4 : (quads % 2 == 0 ? 2 : 1));
+}
+
+template <int THREADS, int KPT, bool KEEP_DIGITS>
+__device__ __forceinline__ void ScatterStagedKeys(const uint32_t* sorted, const uint32_t* offset, uint32_t* out,
+                                                  uint32_t valid, uint32_t shift, int tid, uint32_t boundaryQuad,
+                                                  uint32_t (&digits)[KEEP_DIGITS ? KPT / 4 : 1],
+                                                  uint32_t& boundaryDigits, uint32_t linearBase = 0) {
+  constexpr uint32_t STAGE = THREADS * KPT;
+  constexpr int B = ScatterBatch<KPT, KEEP_DIGITS>();
+#pragma unroll
+  for (int j0 = 0; j0 < KPT / 4; j0 += B) {
+    u32x4 k4[B];
+    uint32_t o[B];
+    bool whole[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) k4[b] = *reinterpret_cast<const u32x4*>(&sorted[4u * (tid + (j0 + b) * THREADS)]);
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const uint32_t p = StagingSlot<STAGE>(4u * (tid + (j0 + b) * THREADS));  // involution: the sorted position
+      const uint32_t d0 = (k4[b][0] >> shift) & 0xFFu, d3 = (k4[b][3] >> shift) & 0xFFu;
+      whole[b] = (kAblate & 32u) || (p + 3 < valid && d0 == d3);
+      o[b] = (kAblate & 4u) ? linearBase + p : offset[d0] + p;
+      asm volatile("" : "+v"(o[b]));  // fetched here, for every quad: not sunk into the conditional store
+      if (KEEP_DIGITS) digits[j0 + b] = d0 | (d3 << 8);
+    }
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+      if (whole[b]) *reinterpret_cast<u32x4_a4*>(reinterpret_cast<char*>(out) + (uint64_t)(o[b] * 4u)) = k4[b];
+  }
+  if (boundaryQuad != ~0u) {
+    const u32x4 k4 = *reinterpret_cast<const u32x4*>(&sorted[StagingSlot<STAGE>(boundaryQuad)]);
+    boundaryDigits = ((k4[0] >> shift) & 0xFFu) | (((k4[1] >> shift) & 0xFFu) << 8) |
+                     (((k4[2] >> shift) & 0xFFu) << 16) | (((k4[3] >> shift) & 0xFFu) << 24);
+    StoreBoundaryQuad<STAGE>(sorted, offset, out, boundaryQuad, valid, boundaryDigits, linearBase);
+  }
+}
+
+template <int THREADS, int KPT>
+__device__ __forceinline__ void ScatterStagedValues(const uint32_t* sorted, const uint32_t* offset, uint32_t* out,
+                                                    uint32_t valid, int tid, uint32_t boundaryQuad,
+                                                    const uint32_t (&digits)[KPT / 4], uint32_t boundaryDigits,
+                                                    uint32_t linearBase = 0) {
+  constexpr uint32_t STAGE = THREADS * KPT;
+  constexpr int B = ScatterBatch<KPT, false>();
+#pragma unroll
+  for (int j0 = 0; j0 < KPT / 4; j0 += B) {
+    u32x4 v4[B];
+    uint32_t o[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const uint32_t p = StagingSlot<STAGE>(4u * (tid + (j0 + b) * THREADS));
+      o[b] = (kAblate & 4u) ? linearBase + p : offset[digits[j0 + b] & 0xFFu] + p;
+      v4[b] = *reinterpret_cast<const u32x4*>(&sorted[4u * (tid + (j0 + b) * THREADS)]);
+      asm volatile("" : "+v"(o[b]));
+    }
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const uint32_t p = StagingSlot<STAGE>(4u * (tid + (j0 + b) * THREADS));
+      const uint32_t d0 = digits[j0 + b] & 0xFFu, d3 = digits[j0 + b] >> 8;
+      if ((kAblate & 32u) || (p + 3 < valid && d0 == d3))
+        *reinterpret_cast<u32x4_a4*>(reinterpret_cast<char*>(out) + (uint64_t)(o[b] * 4u)) = v4[b];
+    }
+  }
+  if (boundaryQuad != ~0u)
+    StoreBoundaryQuad<STAGE>(sorted, offset, out, boundaryQuad, valid, boundaryDigits, linearBase);
+}
+
 // Key+value tiles replay the permutation for the values through the SAME staging buffer after the
 // keys have left it (like the reference, downsweep.slang:208-224): the LDS footprint equals the
 // keys-only one, so two workgroups fit per CU (keys and values staged together would need 128 KiB
@@ -620,57 +739,19 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
     if (!a.earlyValues) LoadStriped<KPT>(a.valuesIn, loadBase, n, valid == TILE, 0u, val);
   }
 
-  // ---- scatter: four consecutive sorted positions per lane ------------------------------------
-  // The staging buffer is sorted by digit, so the four keys of a quad almost always share their
-  // digit (runs are 64-128 keys on uniform data) and go to four consecutive words: one 16-byte LDS read
-  // and one 16-byte store (4-byte aligned: gfx950 global stores need no natural alignment) instead of
-  // four of each; consecutive lanes still cover consecutive addresses.  A quad that straddles a run
-  // boundary or the ragged end falls back to single stores.
-  uint32_t digits[KV ? KPT / 4 : 1];  // key+value: the quad's four digits, for the value phase
-#pragma unroll
-  for (int j = 0; j < KPT / 4; ++j) {
-    const uint32_t slot = 4u * (tid + j * THREADS);
-    const uint32_t p = StagingSlot<TILE>(slot);  // involution: the sorted position of this quad
-    const u32x4 k4 = *reinterpret_cast<const u32x4*>(&sorted[slot]);
-    const uint32_t d0 = (k4[0] >> a.shift) & 0xFFu, d1 = (k4[1] >> a.shift) & 0xFFu;
-    const uint32_t d2 = (k4[2] >> a.shift) & 0xFFu, d3 = (k4[3] >> a.shift) & 0xFFu;
-    if (p + 3 < valid && d0 == d3) {
-      const uint32_t o = (kAblate & 4u) ? tileStart + p : tileOffset[d0] + p;
-      *reinterpret_cast<u32x4_a4*>(a.keysOut + o) = k4;
-    } else {
-      const uint32_t dd[4] = {d0, d1, d2, d3};
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (p + c < valid) a.keysOut[((kAblate & 4u) ? tileStart : tileOffset[dd[c]]) + p + c] = k4[c];
-    }
-    if (KV) {
-      digits[j] = d0 | (d1 << 8) | (d2 << 16) | (d3 << 24);
-      // values and positions are live here: keep the scheduler from batching all the LDS reads
-      if (j % 2 == 1) __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  if (KV) {
+  // ---- scatter (ScatterStagedKeys above); key+value replays the permutation for the values ------
+  uint32_t digits[KV ? KPT / 4 : 1];  // key+value: first and last digit of every quad, for the value phase
+  uint32_t boundaryDigits = 0;
+  const uint32_t boundaryQuad = BoundaryQuad(tid, tileExclusive, count, valid);
+  ScatterStagedKeys<THREADS, KPT, KV>(sorted, tileOffset, a.keysOut, valid, a.shift, tid, boundaryQuad, digits,
+                                      boundaryDigits, tileStart);
+  if constexpr (KV) {
     LdsBarrier();  // every key has left the staging buffer
 #pragma unroll
     for (int i = 0; i < KPT; ++i) sorted[(packedPos[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
     LdsBarrier();
-#pragma unroll
-    for (int j = 0; j < KPT / 4; ++j) {
-      const uint32_t slot = 4u * (tid + j * THREADS);
-      const uint32_t p = StagingSlot<TILE>(slot);
-      const u32x4 v4 = *reinterpret_cast<const u32x4*>(&sorted[slot]);
-      const uint32_t d0 = digits[j] & 0xFFu, d3 = digits[j] >> 24;
-      if (p + 3 < valid && d0 == d3) {
-        const uint32_t o = (kAblate & 4u) ? tileStart + p : tileOffset[d0] + p;
-        *reinterpret_cast<u32x4_a4*>(a.valuesOut + o) = v4;
-      } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const uint32_t d = (digits[j] >> (8 * c)) & 0xFFu;
-          if (p + c < valid) a.valuesOut[((kAblate & 4u) ? tileStart : tileOffset[d]) + p + c] = v4[c];
-        }
-      }
-    }
+    ScatterStagedValues<THREADS, KPT>(sorted, tileOffset, a.valuesOut, valid, tid, boundaryQuad, digits,
+                                      boundaryDigits, tileStart);
   }
 #ifdef VRDX_TRACE
   VRDX_STAMP(6);
@@ -712,56 +793,6 @@ constexpr int PairMinWavesPerSimd() {
   constexpr int workgroups = (int)((160 * 1024) / (PairLdsWords<THREADS, KPT>() * 4));
   constexpr int waves = workgroups * THREADS / 256;
   return waves > 8 ? 8 : (waves < 1 ? 1 : waves);
-}
-
-// Quad scatter of one staged sub-tile (see onesweep_kernel's scatter stage).
-template <int THREADS, int KPT, bool KEEP_DIGITS>
-__device__ __forceinline__ void ScatterStagedKeys(const uint32_t* sorted, const uint32_t* offset, uint32_t* out,
-                                                  uint32_t valid, uint32_t shift, int tid,
-                                                  uint32_t (&digits)[KEEP_DIGITS ? KPT / 4 : 1]) {
-  constexpr uint32_t STAGE = THREADS * KPT;
-#pragma unroll
-  for (int j = 0; j < KPT / 4; ++j) {
-    const uint32_t slot = 4u * (tid + j * THREADS);
-    const uint32_t p = StagingSlot<STAGE>(slot);
-    const u32x4 k4 = *reinterpret_cast<const u32x4*>(&sorted[slot]);
-    const uint32_t d0 = (k4[0] >> shift) & 0xFFu, d1 = (k4[1] >> shift) & 0xFFu;
-    const uint32_t d2 = (k4[2] >> shift) & 0xFFu, d3 = (k4[3] >> shift) & 0xFFu;
-    if (p + 3 < valid && d0 == d3) {
-      *reinterpret_cast<u32x4_a4*>(out + offset[d0] + p) = k4;
-    } else {
-      const uint32_t dd[4] = {d0, d1, d2, d3};
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (p + c < valid) out[offset[dd[c]] + p + c] = k4[c];
-    }
-    if (KEEP_DIGITS) {
-      digits[j] = d0 | (d1 << 8) | (d2 << 16) | (d3 << 24);
-      if (j % 2 == 1) __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-}
-
-template <int THREADS, int KPT>
-__device__ __forceinline__ void ScatterStagedValues(const uint32_t* sorted, const uint32_t* offset, uint32_t* out,
-                                                    uint32_t valid, int tid, const uint32_t (&digits)[KPT / 4]) {
-  constexpr uint32_t STAGE = THREADS * KPT;
-#pragma unroll
-  for (int j = 0; j < KPT / 4; ++j) {
-    const uint32_t slot = 4u * (tid + j * THREADS);
-    const uint32_t p = StagingSlot<STAGE>(slot);
-    const u32x4 v4 = *reinterpret_cast<const u32x4*>(&sorted[slot]);
-    const uint32_t d0 = digits[j] & 0xFFu, d3 = digits[j] >> 24;
-    if (p + 3 < valid && d0 == d3) {
-      *reinterpret_cast<u32x4_a4*>(out + offset[d0] + p) = v4;
-    } else {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const uint32_t d = (digits[j] >> (8 * c)) & 0xFFu;
-        if (p + c < valid) out[offset[d] + p + c] = v4[c];
-      }
-    }
-  }
 }
 
 template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK>
@@ -911,17 +942,23 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
 
   // ---- scatter A ---------------------------------------------------------------------------------
   uint32_t digits[KV ? KPT / 4 : 1];
+  uint32_t boundaryDigits = 0;
+  const uint32_t boundaryQuadA = BoundaryQuad(tid, localA, countA, validA);
+  const uint32_t boundaryQuadB = BoundaryQuad(tid, localB, countB, validB);
   if constexpr (KV) {
     uint32_t val[KPT];
     LoadStriped<KPT>(a.valuesIn, loadBaseA, n, validA == SUB, 0u, val);  // pad: downsweep.slang:85
-    ScatterStagedKeys<THREADS, KPT, true>(sorted, offsetA, a.keysOut, validA, a.shift, tid, digits);
+    ScatterStagedKeys<THREADS, KPT, true>(sorted, offsetA, a.keysOut, validA, a.shift, tid, boundaryQuadA, digits,
+                                          boundaryDigits);
     LdsBarrier();
 #pragma unroll
     for (int i = 0; i < KPT; ++i) sorted[(packedPosA[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
     LdsBarrier();
-    ScatterStagedValues<THREADS, KPT>(sorted, offsetA, a.valuesOut, validA, tid, digits);
+    ScatterStagedValues<THREADS, KPT>(sorted, offsetA, a.valuesOut, validA, tid, boundaryQuadA, digits,
+                                      boundaryDigits);
   } else {
-    ScatterStagedKeys<THREADS, KPT, false>(sorted, offsetA, a.keysOut, validA, a.shift, tid, digits);
+    ScatterStagedKeys<THREADS, KPT, false>(sorted, offsetA, a.keysOut, validA, a.shift, tid, boundaryQuadA, digits,
+                                           boundaryDigits);
   }
   LdsBarrier();  // the staging buffer is free again
 
@@ -932,14 +969,17 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
   if constexpr (KV) {
     uint32_t val[KPT];
     LoadStriped<KPT>(a.valuesIn, loadBaseB, n, validB == SUB, 0u, val);
-    ScatterStagedKeys<THREADS, KPT, true>(sorted, offsetB, a.keysOut, validB, a.shift, tid, digits);
+    ScatterStagedKeys<THREADS, KPT, true>(sorted, offsetB, a.keysOut, validB, a.shift, tid, boundaryQuadB, digits,
+                                          boundaryDigits);
     LdsBarrier();
 #pragma unroll
     for (int i = 0; i < KPT; ++i) sorted[(packedPosB[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
     LdsBarrier();
-    ScatterStagedValues<THREADS, KPT>(sorted, offsetB, a.valuesOut, validB, tid, digits);
+    ScatterStagedValues<THREADS, KPT>(sorted, offsetB, a.valuesOut, validB, tid, boundaryQuadB, digits,
+                                      boundaryDigits);
   } else {
-    ScatterStagedKeys<THREADS, KPT, false>(sorted, offsetB, a.keysOut, validB, a.shift, tid, digits);
+    ScatterStagedKeys<THREADS, KPT, false>(sorted, offsetB, a.keysOut, validB, a.shift, tid, boundaryQuadB, digits,
+                                           boundaryDigits);
   }
 #ifdef VRDX_TRACE
   VRDX_STAMP(6);
