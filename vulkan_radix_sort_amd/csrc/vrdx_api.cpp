@@ -137,6 +137,12 @@ void DumpTrace() {
 }
 #endif
 
+// Integer environment knob for the tuning scripts (read once); -1 when unset.
+int TuningKnob(const char* name) {
+  const char* env = std::getenv(name);
+  return env != nullptr ? std::atoi(env) : -1;
+}
+
 inline uint8_t* BufferAddress(VkBuffer buffer, VkDeviceSize offset) {
   return reinterpret_cast<uint8_t*>(buffer) + offset;
 }
@@ -232,7 +238,8 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     const uint32_t cap = (uint32_t)sorter->computeUnits * vrdx::kHistWorkgroupsPerCu;
     if (grid > cap) grid = cap;
     if (grid == 0) grid = 1;
-    if (const char* env = std::getenv("VRDX_HIST_GRID")) grid = (uint32_t)std::atoi(env) > 0 ? (uint32_t)std::atoi(env) : grid;  // tuning
+    static const int forcedGrid = TuningKnob("VRDX_HIST_GRID");  // tools/hist_grid.sh
+    if (forcedGrid > 0) grid = (uint32_t)forcedGrid;
     vrdx::LaunchHistogram(stream, grid, keys, elementCount, countPtr, globalHistogram);
     DebugCheck("histogram_kernel");
   }
@@ -243,7 +250,8 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   // wins by 3-11 % for every geometry up to about three rounds of 32768-key tiles per CU, late by
   // 1-3 % beyond.
   bool earlyValues = (double)elementCount <= 3.1 * 32768.0 * (double)sorter->computeUnits;
-  if (const char* env = std::getenv("VRDX_KV_EARLY_VALUES")) earlyValues = env[0] == '1';  // tuning/testing
+  static const int forcedEarly = TuningKnob("VRDX_KV_EARLY_VALUES");  // 0 | 1: tuning/testing
+  if (forcedEarly >= 0) earlyValues = forcedEarly != 0;
   for (uint32_t pass = 0; pass < VRDX_PASSES; ++pass) {
     Stamp(pool, query + 2 + 3 * pass + 0, stream);  // "upsweep" of this pass
     Stamp(pool, query + 2 + 3 * pass + 1, stream);  // "spine" (fused into the onesweep look-back)
