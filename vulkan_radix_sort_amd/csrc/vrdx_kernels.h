@@ -23,8 +23,12 @@ constexpr uint32_t kHistWorkgroupsPerCu = VRDX_HIST_WGS_PER_CU;
 constexpr uint32_t kHistCopiesLarge = 32;          // sorts of kHistManyCopiesFrom keys and more
 constexpr uint32_t kHistManyCopiesFrom = 1u << 24;
 constexpr uint32_t HistLdsBytes(uint32_t copies) { return 4u * 256u * copies * 4u; }  // [pass][digit][copy]
-// keys one histogram workgroup handles per loop trip (kHistThreads lanes x 4 uint4 x 4 keys)
-constexpr uint32_t kHistKeysPerTrip = kHistThreads * 4 * 4;
+#ifndef VRDX_HIST_UNROLL
+#define VRDX_HIST_UNROLL 4
+#endif
+constexpr uint32_t kHistUnroll = VRDX_HIST_UNROLL;  // 16-byte loads in flight per lane
+// keys one histogram workgroup handles per loop trip (kHistThreads lanes x kHistUnroll uint4 x 4 keys)
+constexpr uint32_t kHistKeysPerTrip = kHistThreads * kHistUnroll * 4;
 
 struct TileConfig {
   int threads;

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t*
 
   const uint32_t nvec = n >> 2;
   const uint4* keys4 = reinterpret_cast<const uint4*>(keys);
-  constexpr uint32_t kUnroll = 4;
+  constexpr uint32_t kUnroll = kHistUnroll;
   const uint32_t chunk = kHistThreads * kUnroll;
   for (uint32_t base = blockIdx.x * chunk; base < nvec; base += gridDim.x * chunk) {
     uint4 k[kUnroll];
