@@ -54,7 +54,7 @@ def timed_sorts(torch, dist, sorter, n, steps, warmup, key_value, device, distri
     stream = torch.cuda.current_stream().cuda_stream
     req = sorter.key_value_storage_requirements(n) if key_value else sorter.storage_requirements(n)
     storage = torch.empty(req.size, dtype=torch.uint8, device=device)
-    total = steps + warmup
+    total = warmup + 2 * steps   # warm-up | the K timed steps | K more, each bracketed by events
     seed0 = 1000 * (int(os.environ.get("RANK", "0")) + 1)
     keys = [random_u32(torch, n, seed0 + i, device) for i in range(total)]
     values = [random_u32(torch, n, seed0 + 500 + i, device) for i in range(total)] if key_value else None
@@ -68,22 +68,27 @@ def timed_sorts(torch, dist, sorter, n, steps, warmup, key_value, device, distri
 
     for i in range(warmup):
         one(i)
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for s in range(steps):
-        starts[s].record()
+    for s in range(steps):      # the timed region: exactly K sorts, nothing else on the stream
         one(warmup + s)
-        ends[s].record()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # per-sort GPU time (median reported next to the headline): K more sorts on fresh data, outside
+    # the timed region, each between two events on the sort's stream
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    for s in range(steps):
+        starts[s].record()
+        one(warmup + steps + s)
+        ends[s].record()
+    torch.cuda.synchronize()
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
