@@ -75,8 +75,8 @@ int ForcedConfigIndex() {
 //    multiple of the CU count pays for a whole extra round.  f below is the size in such rounds.
 //    16384-key tiles (two workgroups per CU) degrade gracefully in a partial round, so they win in
 //    the lower part of each round interval while the rounds are few;
-//  * the two-sub-tile kernel (65536 keys, keys-only) halves the rounds again: best when f is at or
-//    just below 2 or 4.
+//  * the two-sub-tile kernel (65536 keys, keys-only) halves the rounds again: best when f is in
+//    (1, 2], just below 4 or 6.
 enum : int { kCfg1024x16 = 1, kCfg1024x8 = 3, kCfg1024x32 = 7, kCfg1024x32x2 = 8 };
 
 int ConfigIndex(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount) {
@@ -91,15 +91,17 @@ int ConfigIndex(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount
     if (f <= 4.0 && intoRound > 0.0 && intoRound <= 0.45) return kCfg1024x16;
     return kCfg1024x32;
   }
-  if (f <= 0.13) return kCfg1024x8;
-  if (f <= 0.6) return kCfg1024x16;
+  if (f <= 0.125) return kCfg1024x8;
+  if (f <= 0.55) return kCfg1024x16;
   if (f <= 1.0) return kCfg1024x32;
   // the two-sub-tile kernel holds two sub-tiles' keys in registers: only with the one-atomic ranking
   const int pair = sorter->atomicRank ? kCfg1024x32x2 : kCfg1024x32;
-  if (f <= 2.0) return pair;
-  if (f <= 3.6) return kCfg1024x16;
-  if (f <= 4.0) return pair;
-  if (f <= 4.5) return kCfg1024x16;
+  if (f <= 2.0) return pair;           // one round of 65536-key tiles instead of two of 32768
+  if (f <= 2.6) return kCfg1024x16;    // just past a round boundary
+  if (f <= 3.1) return kCfg1024x32;
+  if (f <= 3.4) return kCfg1024x16;
+  if (f <= 4.0) return pair;           // two rounds instead of four
+  if (f > 5.0 && f <= 5.8) return pair;  // three instead of six
   return kCfg1024x32;
 }
 
