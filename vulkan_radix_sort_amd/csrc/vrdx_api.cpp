@@ -83,12 +83,11 @@ int ConfigIndex(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount
   const int forced = ForcedConfigIndex();
   if (forced >= 0) return forced;
   const double f = (double)elementCount / ((double)sorter->computeUnits * 32768.0);
-  const double intoRound = f - std::floor(f);  // 0 = exactly full rounds
   if (keyValue) {
     if (f <= 0.26) return kCfg1024x8;
     if (f <= 0.53) return kCfg1024x16;
     if (f <= 1.0) return kCfg1024x32;
-    if (f <= 4.0 && intoRound > 0.0 && intoRound <= 0.45) return kCfg1024x16;
+    if (f <= 1.45) return kCfg1024x16;  // just past the first round boundary (1-3 %)
     return kCfg1024x32;
   }
   if (f <= 0.125) return kCfg1024x8;
