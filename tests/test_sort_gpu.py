@@ -313,7 +313,7 @@ def test_capturable_into_a_hip_graph(torch_mod, sorter, oracle):
 # one size inside every regime of the size-adaptive tile selection (ConfigIndex in vrdx_api.cpp; f =
 # N / (256 CUs * 32768)): 1024x8 | 1024x16 | 1024x32 | two-sub-tile 1024x32x2 | 1024x16 between
 # rounds | ... -- all ragged (odd) sizes
-BREAK_POINT_SIZES = [int(f * (1 << 23)) + 12345 for f in (0.10, 0.20, 0.40, 0.58, 0.80, 1.2, 1.6, 1.99, 2.3)] + \
+BREAK_POINT_SIZES = [int(f * (1 << 23)) + 12345 for f in (0.10, 0.20, 0.40, 0.58, 0.80, 1.2, 1.6, 1.99, 2.3, 2.8, 3.3)] + \
                     [(1 << 24), (1 << 24) + 1, (1 << 23) + 1]
 
 
