@@ -463,6 +463,30 @@ def test_native_soak_overlapping_sorts(torch_mod):
     assert r.returncode == 0 and ", 0 failures" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_general_path_at_small_sizes(torch_mod):
+    """Sorts of <= 16384 elements normally take the single-workgroup kernel; VRDX_SMALL_SORT=0 sends
+    them down the general path (clear + histogram + four onesweep passes), which must stay parity-clean
+    at those sizes too (1-element sorts, ragged single tiles, indirect counts of 0)."""
+    exe = os.path.join(ROOT, "tests", "native", "vrdx_selftest")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.dirname(exe)], check=True)
+    env = dict(os.environ, VRDX_SMALL_SORT="0")
+    r = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and ", 0 failures" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("n", [1, 255, 4096, 4097, 16383, 16384, 16385])
+def test_small_sort_boundary_sizes(torch_mod, sorter, oracle, n):
+    """Either side of the single-workgroup kernel's limits (4096: 256-thread form, 16384: 1024-thread
+    form, 16385: general path), duplicate-heavy keys (8 significant bits) so that stability is visible,
+    direct and indirect."""
+    k, _ = oracle.generate(5, n, 8)
+    iota = np.arange(n, dtype=np.uint32)
+    check_against_oracle(torch_mod, sorter, oracle, k)
+    check_against_oracle(torch_mod, sorter, oracle, k, iota)
+    check_against_oracle(torch_mod, sorter, oracle, k, iota, count=max(n - 3, 0), indirect=True, max_count=n)
+
+
 @pytest.mark.parametrize("config", ["1024x16", "512x32", "1024x8", "512x16", "512x24", "1024x32", "1024x32x2", "512x32x2"])
 def test_other_tile_configs(torch_mod, oracle, config):
     """Every compiled tile geometry is parity-clean, not only the default one."""

@@ -138,6 +138,14 @@ void DumpTrace() {
 }
 #endif
 
+bool SmallSortEnabled() {
+  static const bool enabled = [] {
+    const char* env = std::getenv("VRDX_SMALL_SORT");  // "0": always take the general path (testing)
+    return env == nullptr || env[0] != '0';
+  }();
+  return enabled;
+}
+
 // Integer environment knob for the tuning scripts (read once); -1 when unset.
 int TuningKnob(const char* name) {
   const char* env = std::getenv(name);
@@ -208,6 +216,19 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   if (elementCount == 0) {
     // reference: zero partitions -> every dispatch is empty (:353,448,465,487)
     for (uint32_t s = 1; s < 15; ++s) Stamp(pool, query + s, stream);
+    return;
+  }
+
+  // Small sorts: one workgroup, one launch, nothing but the caller's keys / values and the failure
+  // word touched (the
+  // general path below costs six launches = 30-45 us however small N is).  Forcing a tile geometry
+  // (VRDX_TILE_CONFIG) also forces the general path, which is how the tests reach it at small sizes.
+  if (elementCount <= vrdx::kSmallSortMaxElements && ForcedConfigIndex() < 0 && SmallSortEnabled()) {
+    for (uint32_t s = 1; s < 14; ++s) Stamp(pool, query + s, stream);
+    vrdx::LaunchSmallSort(stream, sorter->atomicRank, keys, values, elementCount, countPtr,
+                          reinterpret_cast<uint32_t*>(storage + layout.failureOffset));
+    DebugCheck("small_sort_kernel");
+    Stamp(pool, query + 14, stream);
     return;
   }
 
@@ -319,6 +340,7 @@ VkResult vrdxCreateSorter(const VrdxSorterCreateInfo* pCreateInfo, VrdxSorter* p
   (void)hipGetDevice(&previous);
   hipError_t e = hipSetDevice(ordinal);
   for (int i = 0; i < vrdx::kNumTileConfigs && e == hipSuccess; ++i) e = vrdx::PrepareKernels(i);
+  if (e == hipSuccess) e = vrdx::PrepareSmallSort();
   if (e == hipSuccess) {
     // Ranking mode: the single-atomic form needs a hardware property the ISA manual does not
     // promise, so it is verified here, once, on this very device; VRDX_RANK=ballot|atomic|auto.

@@ -68,6 +68,13 @@ void LaunchHistogram(hipStream_t stream, uint32_t grid, const uint32_t* keys, ui
 void LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool keyValue, bool atomicRank,
                     const OnesweepArgs& args);
 
+// Small sorts (maxCount <= kSmallSortMaxElements): the whole sort in one workgroup and one launch,
+// in place in keys / values (values == nullptr: keys-only); of the storage only *failure is written (0).
+constexpr uint32_t kSmallSortMaxElements = 16384;
+hipError_t PrepareSmallSort();
+void LaunchSmallSort(hipStream_t stream, bool atomicRank, uint32_t* keys, uint32_t* values, uint32_t maxCount,
+                     const uint32_t* countPtr, uint32_t* failure);
+
 // Runs the device self-check of the LDS same-address atomic ordering on the current device
 // (synchronous, ~1 ms).  *laneOrdered = true when returning atomics are served in lane order.
 hipError_t LdsOrderCheck(bool* laneOrdered);

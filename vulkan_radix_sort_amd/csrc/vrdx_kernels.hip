@@ -993,6 +993,101 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
 }
 
 // ---------------------------------------------------------------------------------------------
+// small_sort_kernel: the whole sort in ONE workgroup and ONE launch
+// ---------------------------------------------------------------------------------------------
+// Below ~16 K elements the six launches of the general path (clear, histogram, four passes) cost
+// 30-45 us whatever N is: every launch is one tile's latency chain.  Here one workgroup keeps the
+// keys (and values) in registers, and each of the four passes ranks them (the same wave-private
+// counters and RankAtomic / RankBallot as the tile kernels), scans the 256 digit counts, moves the
+// elements through an LDS staging buffer to their sorted positions and reads them back in
+// wave-striped order.  No global histogram, no tickets, no status words; of the storage only the failure word is written.
+// Positions >= n hold 0xFFFFFFFF pads (value 0): they are last in memory order and carry the
+// largest key, so the stable sort leaves them behind the n real elements, which are what is stored.
+template <int THREADS, int KPT, bool KV>
+constexpr size_t SmallSortLdsWords() {
+  return (size_t)THREADS * KPT * (KV ? 2 : 1) + (size_t)(THREADS / 64) * 256 + 16;
+}
+
+template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK>
+__global__ __launch_bounds__(THREADS) void small_sort_kernel(uint32_t* keys, uint32_t* values, uint32_t maxCount,
+                                                              const uint32_t* countPtr, uint32_t* failure) {
+  constexpr int WAVES = THREADS / 64;
+  constexpr uint32_t TILE = THREADS * KPT;
+  static_assert(THREADS >= 256 && THREADS % 256 == 0, "one thread per digit");
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  uint32_t* const stagedKeys = smem;                              // TILE
+  uint32_t* const stagedValues = smem + TILE;                     // TILE (key+value)
+  uint32_t* const waveHist = smem + TILE * (KV ? 2 : 1);          // WAVES x 256
+  uint32_t* const scanScratch = waveHist + WAVES * 256;           // 8
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  uint32_t* const myHist = waveHist + wave * 256;
+  const uint32_t n = ElementCount(maxCount, countPtr);
+  const uint32_t first = wave * (KPT * 64) + lane;  // element i of this lane: first + 64 * i
+  if (tid == 0) *failure = 0;  // the one word of storage vrdxHipReadStatus looks at: nothing here can spin
+
+  uint32_t key[KPT];
+  uint32_t val[KV ? KPT : 1];
+  LoadStriped<KPT>(keys, first, n, n >= TILE, 0xFFFFFFFFu, key);  // pad: downsweep.slang:81
+  if constexpr (KV) LoadStriped<KPT>(values, first, n, n >= TILE, 0u, val);  // pad: downsweep.slang:85
+
+#pragma unroll 1
+  for (uint32_t shift = 0; shift < 32; shift += 8) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) myHist[lane + 64 * i] = 0;  // my own row: no barrier needed before ranking
+    uint32_t rank[KPT];
+    if constexpr (ATOMIC_RANK)
+      RankAtomic<KPT, false>(key, shift, myHist, lane, rank);
+    else
+      RankBallot<KPT>(key, shift, myHist, lane, rank);
+    LdsBarrier();
+
+    uint32_t count = 0;
+    if (tid < 256) {
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) count += waveHist[w * 256 + tid];
+    }
+    const uint32_t exclusive = BlockExclusiveScan256(tid < 256 ? count : 0u, scanScratch, tid);
+    if (tid < 256) {
+      uint32_t run = exclusive;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) {
+        const uint32_t c = waveHist[w * 256 + tid];
+        waveHist[w * 256 + tid] = run;
+        run += c;
+      }
+    }
+    LdsBarrier();
+
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const uint32_t slot = StagingSlot<TILE>(rank[i] + myHist[(key[i] >> shift) & 0xFFu]);
+      stagedKeys[slot] = key[i];
+      if constexpr (KV) stagedValues[slot] = val[i];
+    }
+    LdsBarrier();
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const uint32_t slot = StagingSlot<TILE>(first + 64 * i);
+      key[i] = stagedKeys[slot];
+      if constexpr (KV) val[i] = stagedValues[slot];
+    }
+    // the next pass writes the staging buffers only after two more barriers
+  }
+
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) {
+    const uint32_t index = first + 64 * i;
+    if (index < n) {
+      keys[index] = key[i];
+      if constexpr (KV) values[index] = val[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // device self-check for RankAtomic's precondition
 // ---------------------------------------------------------------------------------------------
 // Every wave ranks pseudo-random digit vectors of several entropies (constant, 2, 4, 16, 256
@@ -1142,6 +1237,58 @@ hipError_t LdsOrderCheck(bool* laneOrdered) {
   (void)hipFree(d);
   if (e == hipSuccess) *laneOrdered = h == 0;
   return e;
+}
+
+// ---- single-launch path for small sorts ---------------------------------------------------------
+template <int THREADS, int KPT>
+static hipError_t PrepareSmall() {
+  const struct {
+    const void* fn;
+    size_t words;
+  } kernels[4] = {
+      {reinterpret_cast<const void*>(&small_sort_kernel<THREADS, KPT, false, false>), SmallSortLdsWords<THREADS, KPT, false>()},
+      {reinterpret_cast<const void*>(&small_sort_kernel<THREADS, KPT, false, true>), SmallSortLdsWords<THREADS, KPT, false>()},
+      {reinterpret_cast<const void*>(&small_sort_kernel<THREADS, KPT, true, false>), SmallSortLdsWords<THREADS, KPT, true>()},
+      {reinterpret_cast<const void*>(&small_sort_kernel<THREADS, KPT, true, true>), SmallSortLdsWords<THREADS, KPT, true>()},
+  };
+  for (const auto& k : kernels) {
+    const hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(k.words * 4));
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+template <int THREADS, int KPT>
+static void LaunchSmall(hipStream_t stream, bool atomicRank, uint32_t* keys, uint32_t* values, uint32_t maxCount,
+                        const uint32_t* countPtr, uint32_t* failure) {
+  const dim3 g(1), b(THREADS);
+  if (values != nullptr) {
+    const size_t lds = SmallSortLdsWords<THREADS, KPT, true>() * 4;
+    if (atomicRank)
+      hipLaunchKernelGGL((small_sort_kernel<THREADS, KPT, true, true>), g, b, lds, stream, keys, values, maxCount, countPtr, failure);
+    else
+      hipLaunchKernelGGL((small_sort_kernel<THREADS, KPT, true, false>), g, b, lds, stream, keys, values, maxCount, countPtr, failure);
+  } else {
+    const size_t lds = SmallSortLdsWords<THREADS, KPT, false>() * 4;
+    if (atomicRank)
+      hipLaunchKernelGGL((small_sort_kernel<THREADS, KPT, false, true>), g, b, lds, stream, keys, values, maxCount, countPtr, failure);
+    else
+      hipLaunchKernelGGL((small_sort_kernel<THREADS, KPT, false, false>), g, b, lds, stream, keys, values, maxCount, countPtr, failure);
+  }
+}
+
+hipError_t PrepareSmallSort() {
+  hipError_t e = PrepareSmall<256, 16>();
+  if (e == hipSuccess) e = PrepareSmall<1024, 16>();
+  return e;
+}
+
+void LaunchSmallSort(hipStream_t stream, bool atomicRank, uint32_t* keys, uint32_t* values, uint32_t maxCount,
+                     const uint32_t* countPtr, uint32_t* failure) {
+  if (maxCount <= 256u * 16u)
+    LaunchSmall<256, 16>(stream, atomicRank, keys, values, maxCount, countPtr, failure);
+  else
+    LaunchSmall<1024, 16>(stream, atomicRank, keys, values, maxCount, countPtr, failure);
 }
 
 void LaunchHistogram(hipStream_t stream, uint32_t grid, const uint32_t* keys, uint32_t maxCount,
