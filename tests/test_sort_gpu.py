@@ -330,6 +330,26 @@ def test_every_size_regime_matches_oracle(torch_mod, sorter, oracle, n):
     assert np.array_equal(gk, ek) and np.array_equal(gp, ep)
 
 
+@pytest.mark.parametrize("n", [70_001, 3_000_001, 9_000_001, (1 << 24) + 5])
+def test_constant_digit_passes_are_copied_correctly(torch_mod, sorter, oracle, n):
+    """A pass whose digit is the same for every key is the identity permutation; the kernels detect it
+    from the global histogram and copy the tile instead of ranking it.  16-bit keys (two such
+    passes), keys with a constant low byte, a constant middle byte, and all-equal keys, in every
+    tile-geometry regime (values = iota: the permutation itself)."""
+    rng = np.random.default_rng(n)
+    r = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+    iota = np.arange(n, dtype=np.uint32)
+    for name, k in (("16-bit", r & np.uint32(0xFFFF)),
+                    ("low byte constant", (r & np.uint32(0xFFFFFF00)) | np.uint32(0x5A)),
+                    ("middle byte constant", (r & np.uint32(0xFF00FFFF)) | np.uint32(0x00C30000)),
+                    ("all equal", np.full(n, 0xDEADBEEF, np.uint32))):
+        ek, ep, _ = oracle.sort(k, iota)
+        gk, _ = gpu_sort(torch_mod, sorter, k)
+        assert np.array_equal(gk, ek), name
+        gk, gp = gpu_sort(torch_mod, sorter, k, iota)
+        assert np.array_equal(gk, ek) and np.array_equal(gp, ep), name
+
+
 @pytest.mark.parametrize("seed", [1, 2])
 def test_full_size_2pow25_properties_and_golden_checksum(torch_mod, sorter, oracle, golden, seed):
     """BASELINE.json configs[1] and [2]: N = 2^25 uniform-random u32, keys-only and key+value."""

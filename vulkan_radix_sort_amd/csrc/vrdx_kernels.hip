@@ -125,6 +125,33 @@ __device__ __forceinline__ void LoadStriped(const uint32_t* base, uint32_t first
   }
 }
 
+// Wave-striped store, the inverse of LoadStriped: base[first + 64 * i] = in[i] where the index is < n.
+template <int KPT>
+__device__ __forceinline__ void StoreStriped(uint32_t* base, uint32_t first, uint32_t n, bool full,
+                                             const uint32_t (&in)[KPT]) {
+  char* const bytes = reinterpret_cast<char*>(base);
+  const uint32_t offset = first * 4u;
+#pragma unroll
+  for (int i = 0; i < KPT; ++i)
+    if (full || first + i * 64 < n)
+      *reinterpret_cast<uint32_t*>(bytes + ((uint64_t)offset + (uint64_t)(i * 256))) = in[i];
+}
+
+// Trivial pass: ONE digit of this pass holds every key (16- or 24-bit keys, constant high bytes,
+// all-equal input), so the pass's stable permutation is the identity and a tile just copies its
+// range -- no ranking, no status words, no look-back (every tile of the launch sees the same global
+// histogram and takes the same branch).  Threads 0..255 each compare one global count with n while
+// the ticket is on its way; flags[0..3] are the four waves' verdicts, read after the barrier that
+// follows.  Must be called by every thread before that barrier.
+__device__ __forceinline__ void PublishTrivialPassVote(const uint32_t* globalHistogram, uint32_t n, int tid,
+                                                       uint32_t* flags) {
+  if (tid < 256) {
+    const bool all = globalHistogram[tid] == n;
+    const uint64_t any = __ballot(all);
+    if ((tid & 63) == 0) flags[tid >> 6] = any != 0ull ? 1u : 0u;
+  }
+}
+
 // Exclusive scan of one value per thread over threads 0..255 (4 waves); other threads pass 0 and
 // ignore the result.  Contains one barrier: every thread of the block must call it.
 __device__ __forceinline__ uint32_t BlockExclusiveScan256(uint32_t v, uint32_t* scratch4, int tid) {
@@ -515,7 +542,9 @@ __device__ __forceinline__ void StoreBoundaryQuad(const uint32_t* sorted, const 
 template <int KPT, bool KV>
 constexpr int ScatterBatch() {
   constexpr int quads = KPT / 4;
-  constexpr int want = KV ? 4 : 8;  // key+value: the values and their slots are live as well
+  // key+value: the values and their slots are live as well (and 1024x16 must stay within the 64
+  // registers that let two workgroups share a CU)
+  constexpr int want = KV ? (KPT >= 32 ? 4 : 2) : 8;
   return quads % want == 0 ? want : (quads % 4 == 0 ? 4 : (quads % 2 == 0 ? 2 : 1));
 }
 
@@ -634,13 +663,15 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
 #endif
   VRDX_STAMP(0);
 
+  const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   if (tid == 0) misc[0] = (kAblate & 8u) ? blockIdx.x : atomicAdd(a.ticketCur, 1u);
+  PublishTrivialPassVote(a.globalHistogram, n, tid, misc + 1);
   for (int i = tid; i < WAVES * 256; i += THREADS) waveHist[i] = 0;
   LdsBarrier();
   VRDX_STAMP(1);
 
   const uint32_t tile = misc[0];
-  const uint32_t n = ElementCount(a.maxCount, a.countPtr);
+  const bool trivialPass = (misc[1] | misc[2] | misc[3] | misc[4]) != 0 && kAblate == 0;
   const uint32_t tiles = (n + TILE - 1) / TILE;
   if (tile >= tiles) return;  // uniform for the whole workgroup
   const bool lastTile = tile == tiles - 1;
@@ -663,6 +694,14 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   // highest memory positions of the tile and have digit 255 in every pass, so the stable ranking
   // puts them at tile-local positions >= valid, where nothing is written.
   LoadStriped<KPT>(a.keysIn, loadBase, n, valid == TILE, 0xFFFFFFFFu, key);
+  if (trivialPass) {  // identity permutation: copy the tile (see PublishTrivialPassVote)
+    StoreStriped<KPT>(a.keysOut, loadBase, n, valid == TILE, key);
+    if constexpr (KV) {
+      LoadStriped<KPT>(a.valuesIn, loadBase, n, valid == TILE, 0u, val);
+      StoreStriped<KPT>(a.valuesOut, loadBase, n, valid == TILE, val);
+    }
+    return;
+  }
 
   // ---- rank inside the wave (memory order) ---------------------------------------------------
   // key+value: ranks / positions live until the values are staged, so they are kept packed two to
@@ -823,13 +862,15 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
 #endif
   VRDX_STAMP(0);
 
+  const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   if (tid == 0) misc[0] = atomicAdd(a.ticketCur, 1u);
+  PublishTrivialPassVote(a.globalHistogram, n, tid, misc + 1);
   for (int i = tid; i < WAVES * 256; i += THREADS) waveHist[i] = 0;
   LdsBarrier();
   VRDX_STAMP(1);
 
   const uint32_t tile = misc[0];
-  const uint32_t n = ElementCount(a.maxCount, a.countPtr);
+  const bool trivialPass = (misc[1] | misc[2] | misc[3] | misc[4]) != 0;
   const uint32_t tiles = (n + TILE - 1) / TILE;
   if (tile >= tiles) return;  // uniform for the whole workgroup
   const bool lastTile = tile == tiles - 1;
@@ -851,6 +892,18 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
   // ---- sub-tile A: load, rank ------------------------------------------------------------------
   uint32_t keyA[KPT];
   LoadStriped<KPT>(a.keysIn, loadBaseA, n, validA == SUB, 0xFFFFFFFFu, keyA);  // pad: downsweep.slang:81
+  if (trivialPass) {  // identity permutation: copy both sub-tiles (see PublishTrivialPassVote)
+    StoreStriped<KPT>(a.keysOut, loadBaseA, n, validA == SUB, keyA);
+    LoadStriped<KPT>(a.keysIn, loadBaseB, n, validB == SUB, 0xFFFFFFFFu, keyA);
+    StoreStriped<KPT>(a.keysOut, loadBaseB, n, validB == SUB, keyA);
+    if constexpr (KV) {
+      LoadStriped<KPT>(a.valuesIn, loadBaseA, n, validA == SUB, 0u, keyA);
+      StoreStriped<KPT>(a.valuesOut, loadBaseA, n, validA == SUB, keyA);
+      LoadStriped<KPT>(a.valuesIn, loadBaseB, n, validB == SUB, 0u, keyA);
+      StoreStriped<KPT>(a.valuesOut, loadBaseB, n, validB == SUB, keyA);
+    }
+    return;
+  }
   uint32_t rankA[PACKED ? KPT / 2 : KPT];
   if constexpr (ATOMIC_RANK)
     RankAtomic<KPT, PACKED>(keyA, a.shift, myHist, lane, rankA);
