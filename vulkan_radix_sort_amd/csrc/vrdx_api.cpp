@@ -232,7 +232,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     return;
   }
 
-  // Clear count/tickets/failure word, the 4x256 global histogram (reference :382) and status
+  // Clear count/failure word, the 4x256 global histogram (reference :382) and status
   // region 0 in one fill.  Indirect: also copy the device-side count to where the reference keeps
   // it (:368-379); the kernels themselves read it straight from the caller's buffer.  (Direct: the
   // count travels as a kernel argument, the slot stays 0 -- storage contents are scratch.)
@@ -262,7 +262,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     if (grid == 0) grid = 1;
     static const int forcedGrid = TuningKnob("VRDX_HIST_GRID");  // tools/hist_grid.sh
     if (forcedGrid > 0) grid = (uint32_t)forcedGrid;
-    vrdx::LaunchHistogram(stream, grid, keys, elementCount, countPtr, globalHistogram);
+    vrdx::LaunchHistogram(stream, grid, keys, elementCount, countPtr, globalHistogram, tickets);
     DebugCheck("histogram_kernel");
   }
 
@@ -279,15 +279,15 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     Stamp(pool, query + 2 + 3 * pass + 1, stream);  // "spine" (fused into the onesweep look-back)
 
     vrdx::OnesweepArgs args;
-    // switch in->out to out->in for pass 1, pass 3 (reference :417-427)
-    const bool odd = (pass & 1u) != 0;
-    args.keysIn = odd ? keysScratch : keys;
-    args.keysOut = odd ? keys : keysScratch;
-    args.valuesIn = keyValue ? (odd ? valuesScratch : values) : nullptr;
-    args.valuesOut = keyValue ? (odd ? values : valuesScratch) : nullptr;
+    // which pair of arrays the pass reads is settled on the device (vrdx_kernels.h); the reference
+    // switches in->out to out->in for pass 1, pass 3 (:417-427) and so do four ranking passes here
+    args.keysCaller = keys;
+    args.keysScratch = keysScratch;
+    args.valuesCaller = keyValue ? values : nullptr;
+    args.valuesScratch = keyValue ? valuesScratch : nullptr;
     args.maxCount = elementCount;
     args.countPtr = countPtr;
-    args.globalHistogram = globalHistogram + pass * VRDX_RADIX;
+    args.histogramTable = globalHistogram;
     args.statusCur = status + (size_t)(pass & 1u) * statusRows * VRDX_RADIX;
     args.statusNext =
         pass + 1 < VRDX_PASSES ? status + (size_t)((pass + 1) & 1u) * statusRows * VRDX_RADIX : nullptr;
@@ -295,7 +295,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     args.ticketCur = tickets + (pass & 1u);
     args.ticketNext = tickets + ((pass + 1) & 1u);
     args.failure = failure;
-    args.shift = 8 * pass;
+    args.pass = pass;
     args.earlyValues = earlyValues ? 1u : 0u;
     args.trace = nullptr;
 #ifdef VRDX_TRACE

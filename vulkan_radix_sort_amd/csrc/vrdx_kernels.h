@@ -40,20 +40,23 @@ constexpr int kNumTileConfigs = 10;
 extern const TileConfig kTileConfigs[kNumTileConfigs];
 
 struct OnesweepArgs {
-  const uint32_t* keysIn;
-  uint32_t* keysOut;
-  const uint32_t* valuesIn;   // KV only
-  uint32_t* valuesOut;        // KV only
+  // The pass reads one pair of arrays and writes the other; which is which is decided ON THE DEVICE
+  // (trivial passes are skipped, see PassPlan in vrdx_kernels.hip): with four ranking passes it is
+  // caller -> scratch on passes 0, 2 and scratch -> caller on 1, 3 (reference :417-427).
+  uint32_t* keysCaller;
+  uint32_t* keysScratch;
+  uint32_t* valuesCaller;     // KV only
+  uint32_t* valuesScratch;    // KV only
   uint32_t maxCount;          // element count (direct) or upper bound (indirect)
   const uint32_t* countPtr;   // device-side element count (indirect) or nullptr
-  const uint32_t* globalHistogram;  // this pass's 256 raw digit counts
+  const uint32_t* histogramTable;  // uint[4][256]: raw digit counts of all four passes
   uint32_t* statusCur;        // status region of this pass: [statusRows][256]
   uint32_t* statusNext;       // region to clear for the next pass, or nullptr on the last pass
   uint32_t statusRows;
   uint32_t* ticketCur;
   uint32_t* ticketNext;
   uint32_t* failure;
-  uint32_t shift;             // 8 * pass
+  uint32_t pass;              // 0..3: digit = (key >> 8 * pass) & 255
   uint32_t earlyValues;       // KV: fetch the values right after the ranking instead of after the look-back
   unsigned long long* trace;  // phase stamps, 8 per tile; nullptr outside tools/trace.sh builds
 };
@@ -61,8 +64,9 @@ struct OnesweepArgs {
 // Raises the dynamic-LDS limit of both instantiations (keys-only, key-value) of one tile config.
 hipError_t PrepareKernels(int configIndex);
 
+// Also zeroes the two tile tickets (they live outside the cleared prefix of the storage).
 void LaunchHistogram(hipStream_t stream, uint32_t grid, const uint32_t* keys, uint32_t maxCount,
-                     const uint32_t* countPtr, uint32_t* globalHistogram);
+                     const uint32_t* countPtr, uint32_t* globalHistogram, uint32_t* tickets);
 
 // atomicRank selects the one-LDS-atomic-per-key ranking; only legal when LdsOrderCheck() said so.
 void LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool keyValue, bool atomicRank,

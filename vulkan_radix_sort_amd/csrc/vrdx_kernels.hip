@@ -137,19 +137,64 @@ __device__ __forceinline__ void StoreStriped(uint32_t* base, uint32_t first, uin
       *reinterpret_cast<uint32_t*>(bytes + ((uint64_t)offset + (uint64_t)(i * 256))) = in[i];
 }
 
-// Trivial pass: ONE digit of this pass holds every key (16- or 24-bit keys, constant high bytes,
-// all-equal input), so the pass's stable permutation is the identity and a tile just copies its
-// range -- no ranking, no status words, no look-back (every tile of the launch sees the same global
-// histogram and takes the same branch).  Threads 0..255 each compare one global count with n while
-// the ticket is on its way; flags[0..3] are the four waves' verdicts, read after the barrier that
-// follows.  Must be called by every thread before that barrier.
-__device__ __forceinline__ void PublishTrivialPassVote(const uint32_t* globalHistogram, uint32_t n, int tid,
-                                                       uint32_t* flags) {
-  if (tid < 256) {
-    const bool all = globalHistogram[tid] == n;
-    const uint64_t any = __ballot(all);
-    if ((tid & 63) == 0) flags[tid >> 6] = any != 0ull ? 1u : 0u;
+// Trivial passes.  If ONE digit of a pass holds every key (16- or 24-bit keys, constant bytes,
+// all-equal input) that pass's stable permutation is the identity.  Every workgroup of every pass
+// reads the whole 4 x 256 table of global counts while its ticket is on its way (one load per thread)
+// and derives the same plan:
+//   * a trivial pass is SKIPPED altogether (the launch returns after its housekeeping) -- the data
+//     stays where it is and the later passes read it from there;
+//   * the result has to end in the caller's buffers, i.e. after an even number of buffer changes; if
+//     the number of non-trivial passes is odd, the first trivial pass does change buffers: its tiles
+//     copy their range (5 TB/s instead of a ranking pass's 3.5).
+// So 16-bit keys cost two passes, all-equal input costs the histogram and four empty launches.
+struct PassPlan {
+  bool skip;         // nothing to do in this launch
+  bool copy;         // identity permutation, but the data has to change buffers
+  bool fromScratch;  // this pass reads the storage's scratch arrays and writes the caller's buffers
+};
+
+// The table loads are issued BEFORE the ticket atomic (LoadPassCounts) and consumed after it
+// (PublishPassVotes): issued after it, wave 0 would wait for the ticket first and then for the loads
+// -- two global round trips on every tile's critical path instead of one (3.3 us instead of 1.8 us
+// before the first barrier at N = 2^23, measured).
+// flags[g] = "some count of group g (64 consecutive counts of the table) equals n".
+template <int THREADS>
+struct PassCounts {
+  uint32_t v[(VRDX_PASSES * VRDX_RADIX) / THREADS];
+};
+
+template <int THREADS>
+__device__ __forceinline__ PassCounts<THREADS> LoadPassCounts(const uint32_t* histogramTable, int tid) {
+  PassCounts<THREADS> c;
+#pragma unroll
+  for (int k = 0; k < (int)(VRDX_PASSES * VRDX_RADIX) / THREADS; ++k) c.v[k] = histogramTable[tid + k * THREADS];
+  return c;
+}
+
+template <int THREADS>
+__device__ __forceinline__ void PublishPassVotes(const PassCounts<THREADS>& c, uint32_t n, int tid, uint32_t* flags) {
+#pragma unroll
+  for (int k = 0; k < (int)(VRDX_PASSES * VRDX_RADIX) / THREADS; ++k) {
+    const uint64_t any = __ballot(c.v[k] == n);
+    if ((tid & 63) == 0) flags[(tid + k * THREADS) >> 6] = any != 0ull ? 1u : 0u;
   }
+}
+
+__device__ __forceinline__ PassPlan ReadPassPlan(const uint32_t* flags, uint32_t pass) {
+  uint32_t trivial = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < VRDX_PASSES; ++q)
+    if ((flags[4 * q] | flags[4 * q + 1] | flags[4 * q + 2] | flags[4 * q + 3]) != 0) trivial |= 1u << q;
+  if (kAblate != 0) trivial = 0;
+  const uint32_t ranked = VRDX_PASSES - (uint32_t)__popc(trivial);
+  // odd number of ranking passes: the first trivial pass copies, so that the result ends at the caller
+  const uint32_t copier = (ranked & 1u) ? (uint32_t)(__ffs(trivial) - 1) : VRDX_PASSES;
+  const uint32_t changes = (~trivial & 15u) | (copier < VRDX_PASSES ? 1u << copier : 0u);
+  PassPlan plan;
+  plan.skip = ((changes >> pass) & 1u) == 0;
+  plan.copy = !plan.skip && ((trivial >> pass) & 1u) != 0;
+  plan.fromScratch = (__popc(changes & ((1u << pass) - 1u)) & 1) != 0;
+  return plan;
 }
 
 // Exclusive scan of one value per thread over threads 0..255 (4 waves); other threads pass 0 and
@@ -190,10 +235,12 @@ template <uint32_t COPIES>
 __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t* __restrict__ keys,
                                                                   uint32_t maxCount,
                                                                   const uint32_t* countPtr,
-                                                                  uint32_t* __restrict__ globalHistogram) {
+                                                                  uint32_t* __restrict__ globalHistogram,
+                                                                  uint32_t* __restrict__ tickets) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* const bins = smem;  // [pass][digit][copy]
   const uint32_t tid = threadIdx.x;
+  if (blockIdx.x == 0 && tid < 2) tickets[tid] = 0;  // outside the cleared prefix of the storage (vrdx_layout.h)
   const uint32_t n = ElementCount(maxCount, countPtr);
 
   for (uint32_t i = tid; i < VRDX_PASSES * VRDX_RADIX * COPIES; i += kHistThreads) bins[i] = 0;
@@ -654,6 +701,7 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   uint32_t* const tileOffset = waveHist + (WAVES - 1) * 256;        // 256: global base - tile-local base (after the regroup)
   uint32_t* const scanScratch = smem;                               // 8   (before the regroup)
   uint32_t* const misc = smem + 8;                                  // [0] ticket (before the regroup)
+  uint32_t* const planFlags = smem + 16;                            // 16 (before the regroup)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -664,14 +712,29 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   VRDX_STAMP(0);
 
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
+  const PassCounts<THREADS> passCounts = LoadPassCounts<THREADS>(a.histogramTable, tid);
   if (tid == 0) misc[0] = (kAblate & 8u) ? blockIdx.x : atomicAdd(a.ticketCur, 1u);
-  PublishTrivialPassVote(a.globalHistogram, n, tid, misc + 1);
+  PublishPassVotes<THREADS>(passCounts, n, tid, planFlags);
   for (int i = tid; i < WAVES * 256; i += THREADS) waveHist[i] = 0;
   LdsBarrier();
   VRDX_STAMP(1);
 
   const uint32_t tile = misc[0];
-  const bool trivialPass = (misc[1] | misc[2] | misc[3] | misc[4]) != 0 && kAblate == 0;
+  const PassPlan plan = ReadPassPlan(planFlags, a.pass);
+  const uint32_t shift = 8u * a.pass;
+  const uint32_t* const keysIn = plan.fromScratch ? a.keysScratch : a.keysCaller;
+  uint32_t* const keysOut = plan.fromScratch ? a.keysCaller : a.keysScratch;
+  const uint32_t* const valuesIn = plan.fromScratch ? a.valuesScratch : a.valuesCaller;
+  uint32_t* const valuesOut = plan.fromScratch ? a.valuesCaller : a.valuesScratch;
+  if (plan.skip) {
+    // Nothing moves in this pass; only the next pass's status rows and ticket are put in order
+    // (workgroup b stands in for tile b: there is no look-back here that would care).
+    if (a.statusNext != nullptr) {
+      if (tid < 256 && blockIdx.x < a.statusRows) a.statusNext[blockIdx.x * VRDX_RADIX + tid] = 0;
+      if (blockIdx.x == 0 && tid == 0) *a.ticketNext = 0;
+    }
+    return;
+  }
   const uint32_t tiles = (n + TILE - 1) / TILE;
   if (tile >= tiles) return;  // uniform for the whole workgroup
   const bool lastTile = tile == tiles - 1;
@@ -693,12 +756,12 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   // Ragged last tile: pad with 0xFFFFFFFF like the reference (downsweep.slang:81).  Pads sit at the
   // highest memory positions of the tile and have digit 255 in every pass, so the stable ranking
   // puts them at tile-local positions >= valid, where nothing is written.
-  LoadStriped<KPT>(a.keysIn, loadBase, n, valid == TILE, 0xFFFFFFFFu, key);
-  if (trivialPass) {  // identity permutation: copy the tile (see PublishTrivialPassVote)
-    StoreStriped<KPT>(a.keysOut, loadBase, n, valid == TILE, key);
+  LoadStriped<KPT>(keysIn, loadBase, n, valid == TILE, 0xFFFFFFFFu, key);
+  if (plan.copy) {  // identity permutation that has to change buffers: copy the tile
+    StoreStriped<KPT>(keysOut, loadBase, n, valid == TILE, key);
     if constexpr (KV) {
-      LoadStriped<KPT>(a.valuesIn, loadBase, n, valid == TILE, 0u, val);
-      StoreStriped<KPT>(a.valuesOut, loadBase, n, valid == TILE, val);
+      LoadStriped<KPT>(valuesIn, loadBase, n, valid == TILE, 0u, val);
+      StoreStriped<KPT>(valuesOut, loadBase, n, valid == TILE, val);
     }
     return;
   }
@@ -711,13 +774,13 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   static_assert(!KV || TILE <= 65536, "packed 16-bit positions");
   uint32_t rank[PACKED ? KPT / 2 : KPT];
   if constexpr (ATOMIC_RANK)
-    RankAtomic<KPT, PACKED>(key, a.shift, waveHist + wave * 256, lane, rank);
+    RankAtomic<KPT, PACKED>(key, shift, waveHist + wave * 256, lane, rank);
   else
-    RankBallot<KPT>(key, a.shift, waveHist + wave * 256, lane, rank);
+    RankBallot<KPT>(key, shift, waveHist + wave * 256, lane, rank);
   ForgetDerivedValues<KPT>(key);
   // key+value, early form: the values start their trip now and land during the scan and the regroup
   if constexpr (KV) {
-    if (a.earlyValues) LoadStriped<KPT>(a.valuesIn, loadBase, n, valid == TILE, 0u, val);  // pad: downsweep.slang:85
+    if (a.earlyValues) LoadStriped<KPT>(valuesIn, loadBase, n, valid == TILE, 0u, val);  // pad: downsweep.slang:85
   }
   LdsBarrier();
   VRDX_STAMP(2);
@@ -735,7 +798,7 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   uint32_t exclusive = 0;
   if (tile == 0) {
     // spine.slang:62-83 equivalent: exclusive scan of this pass's 256 global digit counts.
-    const uint32_t g = tid < 256 ? a.globalHistogram[tid] : 0u;
+    const uint32_t g = tid < 256 ? a.histogramTable[a.pass * VRDX_RADIX + tid] : 0u;
     exclusive = BlockExclusiveScan256(g, scanScratch + 4, tid);
   }
   if (tid < 256) {
@@ -752,7 +815,7 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
 
   // ---- regroup the keys by digit in LDS; key+value keeps the positions for the values ----------
   uint32_t packedPos[KV ? KPT / 2 : 1];
-  RegroupKeys<KPT, TILE, PACKED, KV>(key, rank, a.shift, waveHist + wave * 256, sorted, packedPos);
+  RegroupKeys<KPT, TILE, PACKED, KV>(key, rank, shift, waveHist + wave * 256, sorted, packedPos);
   LdsBarrier();  // waveHist is dead from here on: the look-back reuses it as scratch
   VRDX_STAMP(4);
 
@@ -775,21 +838,21 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   // (2^25: 0.574 vs 0.590 ms).  Issued right before the look-back the loads queue in front of its
   // agent-scope status reads (6 -> 9 us, measured).
   if constexpr (KV) {
-    if (!a.earlyValues) LoadStriped<KPT>(a.valuesIn, loadBase, n, valid == TILE, 0u, val);
+    if (!a.earlyValues) LoadStriped<KPT>(valuesIn, loadBase, n, valid == TILE, 0u, val);
   }
 
   // ---- scatter (ScatterStagedKeys above); key+value replays the permutation for the values ------
   uint32_t digits[KV ? KPT / 4 : 1];  // key+value: first and last digit of every quad, for the value phase
   uint32_t boundaryDigits = 0;
   const uint32_t boundaryQuad = BoundaryQuad(tid, tileExclusive, count, valid);
-  ScatterStagedKeys<THREADS, KPT, KV>(sorted, tileOffset, a.keysOut, valid, a.shift, tid, boundaryQuad, digits,
+  ScatterStagedKeys<THREADS, KPT, KV>(sorted, tileOffset, keysOut, valid, shift, tid, boundaryQuad, digits,
                                       boundaryDigits, tileStart);
   if constexpr (KV) {
     LdsBarrier();  // every key has left the staging buffer
 #pragma unroll
     for (int i = 0; i < KPT; ++i) sorted[(packedPos[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
     LdsBarrier();
-    ScatterStagedValues<THREADS, KPT>(sorted, tileOffset, a.valuesOut, valid, tid, boundaryQuad, digits,
+    ScatterStagedValues<THREADS, KPT>(sorted, tileOffset, valuesOut, valid, tid, boundaryQuad, digits,
                                       boundaryDigits, tileStart);
   }
 #ifdef VRDX_TRACE
@@ -863,14 +926,27 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
   VRDX_STAMP(0);
 
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
+  const PassCounts<THREADS> passCounts = LoadPassCounts<THREADS>(a.histogramTable, tid);
   if (tid == 0) misc[0] = atomicAdd(a.ticketCur, 1u);
-  PublishTrivialPassVote(a.globalHistogram, n, tid, misc + 1);
+  PublishPassVotes<THREADS>(passCounts, n, tid, misc + 1);
   for (int i = tid; i < WAVES * 256; i += THREADS) waveHist[i] = 0;
   LdsBarrier();
   VRDX_STAMP(1);
 
   const uint32_t tile = misc[0];
-  const bool trivialPass = (misc[1] | misc[2] | misc[3] | misc[4]) != 0;
+  const PassPlan plan = ReadPassPlan(misc + 1, a.pass);
+  const uint32_t shift = 8u * a.pass;
+  const uint32_t* const keysIn = plan.fromScratch ? a.keysScratch : a.keysCaller;
+  uint32_t* const keysOut = plan.fromScratch ? a.keysCaller : a.keysScratch;
+  const uint32_t* const valuesIn = plan.fromScratch ? a.valuesScratch : a.valuesCaller;
+  uint32_t* const valuesOut = plan.fromScratch ? a.valuesCaller : a.valuesScratch;
+  if (plan.skip) {  // see onesweep_kernel
+    if (a.statusNext != nullptr) {
+      if (tid < 256 && blockIdx.x < a.statusRows) a.statusNext[blockIdx.x * VRDX_RADIX + tid] = 0;
+      if (blockIdx.x == 0 && tid == 0) *a.ticketNext = 0;
+    }
+    return;
+  }
   const uint32_t tiles = (n + TILE - 1) / TILE;
   if (tile >= tiles) return;  // uniform for the whole workgroup
   const bool lastTile = tile == tiles - 1;
@@ -891,30 +967,30 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
 
   // ---- sub-tile A: load, rank ------------------------------------------------------------------
   uint32_t keyA[KPT];
-  LoadStriped<KPT>(a.keysIn, loadBaseA, n, validA == SUB, 0xFFFFFFFFu, keyA);  // pad: downsweep.slang:81
-  if (trivialPass) {  // identity permutation: copy both sub-tiles (see PublishTrivialPassVote)
-    StoreStriped<KPT>(a.keysOut, loadBaseA, n, validA == SUB, keyA);
-    LoadStriped<KPT>(a.keysIn, loadBaseB, n, validB == SUB, 0xFFFFFFFFu, keyA);
-    StoreStriped<KPT>(a.keysOut, loadBaseB, n, validB == SUB, keyA);
+  LoadStriped<KPT>(keysIn, loadBaseA, n, validA == SUB, 0xFFFFFFFFu, keyA);  // pad: downsweep.slang:81
+  if (plan.copy) {  // identity permutation that has to change buffers: copy both sub-tiles
+    StoreStriped<KPT>(keysOut, loadBaseA, n, validA == SUB, keyA);
+    LoadStriped<KPT>(keysIn, loadBaseB, n, validB == SUB, 0xFFFFFFFFu, keyA);
+    StoreStriped<KPT>(keysOut, loadBaseB, n, validB == SUB, keyA);
     if constexpr (KV) {
-      LoadStriped<KPT>(a.valuesIn, loadBaseA, n, validA == SUB, 0u, keyA);
-      StoreStriped<KPT>(a.valuesOut, loadBaseA, n, validA == SUB, keyA);
-      LoadStriped<KPT>(a.valuesIn, loadBaseB, n, validB == SUB, 0u, keyA);
-      StoreStriped<KPT>(a.valuesOut, loadBaseB, n, validB == SUB, keyA);
+      LoadStriped<KPT>(valuesIn, loadBaseA, n, validA == SUB, 0u, keyA);
+      StoreStriped<KPT>(valuesOut, loadBaseA, n, validA == SUB, keyA);
+      LoadStriped<KPT>(valuesIn, loadBaseB, n, validB == SUB, 0u, keyA);
+      StoreStriped<KPT>(valuesOut, loadBaseB, n, validB == SUB, keyA);
     }
     return;
   }
   uint32_t rankA[PACKED ? KPT / 2 : KPT];
   if constexpr (ATOMIC_RANK)
-    RankAtomic<KPT, PACKED>(keyA, a.shift, myHist, lane, rankA);
+    RankAtomic<KPT, PACKED>(keyA, shift, myHist, lane, rankA);
   else
-    RankBallot<KPT>(keyA, a.shift, myHist, lane, rankA);
+    RankBallot<KPT>(keyA, shift, myHist, lane, rankA);
   ForgetDerivedValues<KPT>(keyA);
 
   // ---- sub-tile B's keys start their trip now ---------------------------------------------------
   __builtin_amdgcn_sched_barrier(0);  // not earlier: A's keys and ranks are live
   uint32_t keyB[KPT];
-  LoadStriped<KPT>(a.keysIn, loadBaseB, n, validB == SUB, 0xFFFFFFFFu, keyB);
+  LoadStriped<KPT>(keysIn, loadBaseB, n, validB == SUB, 0xFFFFFFFFu, keyB);
   LdsBarrier();
   VRDX_STAMP(2);
 
@@ -928,7 +1004,7 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
   uint32_t exclusive = 0;
   if (tile == 0) {
     // spine.slang:62-83 equivalent: exclusive scan of this pass's 256 global digit counts.
-    const uint32_t g = tid < 256 ? a.globalHistogram[tid] : 0u;
+    const uint32_t g = tid < 256 ? a.histogramTable[a.pass * VRDX_RADIX + tid] : 0u;
     exclusive = BlockExclusiveScan256(g, scanScratch + 4, tid);
   }
   if (tid < 256) {
@@ -945,15 +1021,15 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
   // ---- A: regroup into the staging buffer; from here to the next barrier a wave only touches ITS
   // row of the counters, so it can clear the row and rank B without waiting for the others -------
   uint32_t packedPosA[KV ? KPT / 2 : 1];
-  RegroupKeys<KPT, SUB, PACKED, KV>(keyA, rankA, a.shift, myHist, sorted, packedPosA);
+  RegroupKeys<KPT, SUB, PACKED, KV>(keyA, rankA, shift, myHist, sorted, packedPosA);
 #pragma unroll
   for (int i = 0; i < 4; ++i) myHist[lane + 64 * i] = 0;
 
   uint32_t rankB[PACKED ? KPT / 2 : KPT];
   if constexpr (ATOMIC_RANK)
-    RankAtomic<KPT, PACKED>(keyB, a.shift, myHist, lane, rankB);
+    RankAtomic<KPT, PACKED>(keyB, shift, myHist, lane, rankB);
   else
-    RankBallot<KPT>(keyB, a.shift, myHist, lane, rankB);
+    RankBallot<KPT>(keyB, shift, myHist, lane, rankB);
   ForgetDerivedValues<KPT>(keyB);
   LdsBarrier();
   VRDX_STAMP(3);
@@ -1000,38 +1076,38 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
   const uint32_t boundaryQuadB = BoundaryQuad(tid, localB, countB, validB);
   if constexpr (KV) {
     uint32_t val[KPT];
-    LoadStriped<KPT>(a.valuesIn, loadBaseA, n, validA == SUB, 0u, val);  // pad: downsweep.slang:85
-    ScatterStagedKeys<THREADS, KPT, true>(sorted, offsetA, a.keysOut, validA, a.shift, tid, boundaryQuadA, digits,
+    LoadStriped<KPT>(valuesIn, loadBaseA, n, validA == SUB, 0u, val);  // pad: downsweep.slang:85
+    ScatterStagedKeys<THREADS, KPT, true>(sorted, offsetA, keysOut, validA, shift, tid, boundaryQuadA, digits,
                                           boundaryDigits);
     LdsBarrier();
 #pragma unroll
     for (int i = 0; i < KPT; ++i) sorted[(packedPosA[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
     LdsBarrier();
-    ScatterStagedValues<THREADS, KPT>(sorted, offsetA, a.valuesOut, validA, tid, boundaryQuadA, digits,
+    ScatterStagedValues<THREADS, KPT>(sorted, offsetA, valuesOut, validA, tid, boundaryQuadA, digits,
                                       boundaryDigits);
   } else {
-    ScatterStagedKeys<THREADS, KPT, false>(sorted, offsetA, a.keysOut, validA, a.shift, tid, boundaryQuadA, digits,
+    ScatterStagedKeys<THREADS, KPT, false>(sorted, offsetA, keysOut, validA, shift, tid, boundaryQuadA, digits,
                                            boundaryDigits);
   }
   LdsBarrier();  // the staging buffer is free again
 
   // ---- B: regroup, scatter -----------------------------------------------------------------------
   uint32_t packedPosB[KV ? KPT / 2 : 1];
-  RegroupKeys<KPT, SUB, PACKED, KV>(keyB, rankB, a.shift, myHist, sorted, packedPosB);
+  RegroupKeys<KPT, SUB, PACKED, KV>(keyB, rankB, shift, myHist, sorted, packedPosB);
   LdsBarrier();
   if constexpr (KV) {
     uint32_t val[KPT];
-    LoadStriped<KPT>(a.valuesIn, loadBaseB, n, validB == SUB, 0u, val);
-    ScatterStagedKeys<THREADS, KPT, true>(sorted, offsetB, a.keysOut, validB, a.shift, tid, boundaryQuadB, digits,
+    LoadStriped<KPT>(valuesIn, loadBaseB, n, validB == SUB, 0u, val);
+    ScatterStagedKeys<THREADS, KPT, true>(sorted, offsetB, keysOut, validB, shift, tid, boundaryQuadB, digits,
                                           boundaryDigits);
     LdsBarrier();
 #pragma unroll
     for (int i = 0; i < KPT; ++i) sorted[(packedPosB[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
     LdsBarrier();
-    ScatterStagedValues<THREADS, KPT>(sorted, offsetB, a.valuesOut, validB, tid, boundaryQuadB, digits,
+    ScatterStagedValues<THREADS, KPT>(sorted, offsetB, valuesOut, validB, tid, boundaryQuadB, digits,
                                       boundaryDigits);
   } else {
-    ScatterStagedKeys<THREADS, KPT, false>(sorted, offsetB, a.keysOut, validB, a.shift, tid, boundaryQuadB, digits,
+    ScatterStagedKeys<THREADS, KPT, false>(sorted, offsetB, keysOut, validB, shift, tid, boundaryQuadB, digits,
                                            boundaryDigits);
   }
 #ifdef VRDX_TRACE
@@ -1345,13 +1421,13 @@ void LaunchSmallSort(hipStream_t stream, bool atomicRank, uint32_t* keys, uint32
 }
 
 void LaunchHistogram(hipStream_t stream, uint32_t grid, const uint32_t* keys, uint32_t maxCount,
-                     const uint32_t* countPtr, uint32_t* globalHistogram) {
+                     const uint32_t* countPtr, uint32_t* globalHistogram, uint32_t* tickets) {
   if (maxCount >= kHistManyCopiesFrom)
     hipLaunchKernelGGL(histogram_kernel<kHistCopiesLarge>, dim3(grid), dim3(kHistThreads),
-                       HistLdsBytes(kHistCopiesLarge), stream, keys, maxCount, countPtr, globalHistogram);
+                       HistLdsBytes(kHistCopiesLarge), stream, keys, maxCount, countPtr, globalHistogram, tickets);
   else
     hipLaunchKernelGGL(histogram_kernel<kHistCopies>, dim3(grid), dim3(kHistThreads), HistLdsBytes(kHistCopies),
-                       stream, keys, maxCount, countPtr, globalHistogram);
+                       stream, keys, maxCount, countPtr, globalHistogram, tickets);
 }
 
 void LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool keyValue, bool atomicRank,

@@ -6,10 +6,11 @@
 //
 //   byte offset from storageOffset (A = 16)         reference use             our use
 //   [0, 4)                                          element count             element count (direct)
-//   [4, 12)                                         (padding)                 tile tickets[2] (ping-pong)
+//   [4, 12)                                         (padding)                 unused
 //   [12, 16)                                        (padding)                 failure word
 //   [A, A+4096)                                     globalHistogram[4][256]   globalHistogram[4][256] (raw counts)
-//   [A+4096, A+4096+P*1024), P = ceil(N/4096)       partitionHistogram[P][256] tile status[2][rows][256]
+//   [A+4096, A+4096+P*1024), P = ceil(N/4096)       partitionHistogram[P][256] tile status[2][rows][256], then
+//                                                                              (>= 1 KiB is left) tile tickets[2]
 //   16 B                                            (slack of the "4 +" term) unused
 //   inoutOffset = A + HistogramSize(N)              keys scratch uint[N]      keys scratch uint[N]
 //   inoutOffset + Align(InoutSize, A)               values scratch uint[N]    values scratch uint[N]
@@ -21,6 +22,13 @@
 // 2 * (ceil(N/TILE) - 1) KiB <= P KiB, which holds for every N when TILE >= 8192.
 // N <= 2^30 - 4 (the reference's uint32 byte-size math wraps above that, :105-115) keeps every
 // prefix inside 30 bits.
+//
+// The two tile tickets (one per pass parity) sit 512 bytes behind the second status region, in a
+// cache line of their own: every workgroup of a pass hits its ticket with a device-scope atomic, and
+// anything else in that 128-byte line becomes slow to READ meanwhile -- with the tickets in the
+// padding at [4, 12) the line was shared with the first 28 counts of the global histogram, and every
+// pass that read them took 3 us longer (measured: 30.0 vs 27.0 us per pass at N = 2^23).  They are
+// outside the cleared prefix; the histogram kernel zeroes them.
 #ifndef VRDX_LAYOUT_H
 #define VRDX_LAYOUT_H
 
@@ -41,7 +49,6 @@
 
 /* offsets inside the first 16 bytes */
 #define VRDX_OFF_COUNT 0u
-#define VRDX_OFF_TICKETS 4u
 #define VRDX_OFF_FAILURE 12u
 
 #ifdef __cplusplus
@@ -65,7 +72,7 @@ static inline uint64_t InoutSize(uint32_t elementCount, uint32_t align) {
 
 struct StorageLayout {
   uint64_t countOffset;      // element count word
-  uint64_t ticketOffset;     // uint32[2]
+  uint64_t ticketOffset;     // uint32[2], zeroed by the histogram kernel
   uint64_t failureOffset;    // uint32
   uint64_t histogramOffset;  // uint32[4][256]
   uint64_t statusOffset;     // uint32[2][rows][256]
@@ -83,14 +90,15 @@ static inline StorageLayout MakeLayout(uint32_t maxElementCount, uint32_t align,
   const uint64_t histogramSize = HistogramSize(maxElementCount, align);
   const uint64_t inoutSize = InoutSize(maxElementCount, align);
   l.countOffset = VRDX_OFF_COUNT;
-  l.ticketOffset = VRDX_OFF_TICKETS;
   l.failureOffset = VRDX_OFF_FAILURE;
   l.histogramOffset = elementCountSize;
   l.statusOffset = l.histogramOffset + VRDX_PASSES * VRDX_RADIX * sizeof(uint32_t);
   const uint64_t tiles = ((uint64_t)maxElementCount + tileKeys - 1) / tileKeys;
   l.statusRows = tiles > 0 ? tiles - 1 : 0;
-  // count + tickets + failure + global histogram + status region 0
+  // count + failure + global histogram + status region 0
   l.clearBytes = l.statusOffset + l.statusRows * VRDX_RADIX * sizeof(uint32_t);
+  // 2 * rows KiB <= P - 1 KiB for every tile >= 8192 keys: at least 1 KiB is free behind region 1
+  l.ticketOffset = l.statusOffset + 2 * l.statusRows * VRDX_RADIX * sizeof(uint32_t) + 512;
   l.inoutOffset = l.histogramOffset + histogramSize;
   l.valuesOffset = l.inoutOffset + Align((uint32_t)inoutSize, align);
   l.keysOnlySize = l.inoutOffset + inoutSize;
