@@ -15,4 +15,9 @@ mkdir -p $d "$ROOT/gpurun_out"
     -DVRDX_TRACE ${EXTRA_FLAGS:-} -x hip vrdx_kernels.hip vrdx_api.cpp -shared -o $d/libvrdx_hip.so) || exit 1
 LD_LIBRARY_PATH=$d VRDX_TILE_CONFIG=$CONFIG VRDX_TRACE_FILE=$d/trace.bin timeout 120 \
     $ROOT/tests/native/vrdx_selftest trace $LOG2N $KV $PATTERN || exit 1
-python3 $ROOT/tools/trace_report.py $d/trace.bin | tee "$ROOT/gpurun_out/trace_${CONFIG}_${KV}_${PATTERN}.txt"
+{
+  case "$CONFIG" in
+    *x2) echo "# two-sub-tile kernel: the phase labels below read  ticket | load A + rank A | scan A + regroup A + rank B | scan B | look-back | scatter A + regroup B + scatter B" ;;
+  esac
+  python3 $ROOT/tools/trace_report.py $d/trace.bin
+} | tee "$ROOT/gpurun_out/trace_${CONFIG}_${KV}_${PATTERN}.txt"
