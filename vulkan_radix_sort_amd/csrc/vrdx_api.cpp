@@ -73,8 +73,8 @@ int ForcedConfigIndex() {
 //    the 32768 keys whose staging buffer fits the CU's LDS ONCE -- so these tiles run one workgroup
 //    per CU in lock-step ROUNDS of computeUnits tiles, and a sort whose tile count is just above a
 //    multiple of the CU count pays for a whole extra round.  f below is the size in such rounds.
-//    16384-key tiles (two workgroups per CU) degrade gracefully in a partial round, so they win in
-//    the lower part of each round interval while the rounds are few;
+//    16384-key tiles (two workgroups per CU) degrade gracefully in a partial round: key+value sorts
+//    use them just past the first round boundary;
 //  * the two-sub-tile kernel (65536 keys, keys-only) halves the rounds again: best when f is in
 //    (1, 2], just below 4 or 6.
 enum : int { kCfg1024x16 = 1, kCfg1024x8 = 3, kCfg1024x32 = 7, kCfg1024x32x2 = 8 };
@@ -96,11 +96,8 @@ int ConfigIndex(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount
   // the two-sub-tile kernel holds two sub-tiles' keys in registers: only with the one-atomic ranking
   const int pair = sorter->atomicRank ? kCfg1024x32x2 : kCfg1024x32;
   if (f <= 2.0) return pair;           // one round of 65536-key tiles instead of two of 32768
-  if (f <= 2.6) return kCfg1024x16;    // just past a round boundary
-  if (f <= 3.1) return kCfg1024x32;
-  if (f <= 3.4) return kCfg1024x16;
+  if (f <= 3.3) return kCfg1024x32;
   if (f <= 4.0) return pair;           // two rounds instead of four
-  if (f > 5.0 && f <= 5.8) return pair;  // three instead of six
   return kCfg1024x32;
 }
 
