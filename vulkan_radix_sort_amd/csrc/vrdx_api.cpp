@@ -73,8 +73,8 @@ int ForcedConfigIndex() {
 //    the 32768 keys whose staging buffer fits the CU's LDS ONCE -- so these tiles run one workgroup
 //    per CU in lock-step ROUNDS of computeUnits tiles, and a sort whose tile count is just above a
 //    multiple of the CU count pays for a whole extra round.  f below is the size in such rounds.
-//    16384-key tiles (two workgroups per CU) degrade gracefully in a partial round: key+value sorts
-//    use them just past the first round boundary;
+//    (16384-key tiles, two workgroups per CU, degrade gracefully in a partial round and used to win
+//    just past the round boundaries; on the final kernels they no longer do);
 //  * the two-sub-tile kernel (65536 keys, keys-only) halves the rounds again: best when f is in
 //    (1, 2], just below 4 or 6.
 enum : int { kCfg1024x16 = 1, kCfg1024x8 = 3, kCfg1024x32 = 7, kCfg1024x32x2 = 8 };
@@ -86,8 +86,6 @@ int ConfigIndex(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount
   if (keyValue) {
     if (f <= 0.26) return kCfg1024x8;
     if (f <= 0.53) return kCfg1024x16;
-    if (f <= 1.0) return kCfg1024x32;
-    if (f <= 1.45) return kCfg1024x16;  // just past the first round boundary (1-3 %)
     return kCfg1024x32;
   }
   if (f <= 0.125) return kCfg1024x8;
