@@ -262,11 +262,11 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   }
 
   const uint32_t tiles = vrdx::RoundUp(elementCount, tileKeys);
-  // Key+value tiles fetch their values early (right after the ranking) or late (after the look-back),
-  // whichever measured faster (vrdx_selftest sweep, profiles/r01_sweep_kv_early_values.txt): early
-  // wins by 3-11 % for every geometry up to about three rounds of 32768-key tiles per CU, late by
-  // 1-3 % beyond.
-  bool earlyValues = (double)elementCount <= 3.1 * 32768.0 * (double)sorter->computeUnits;
+  // Key+value tiles fetch their values early (right after the ranking: they land during the scan and the
+  // regroup) -- on the final kernels that is as fast as or faster than fetching them after the
+  // look-back at every size (0-8 %, vrdx_selftest sweep with VRDX_KV_EARLY_VALUES=0|1); the late form
+  // stays selectable for measurements.
+  bool earlyValues = true;
   static const int forcedEarly = TuningKnob("VRDX_KV_EARLY_VALUES");  // 0 | 1: tuning/testing
   if (forcedEarly >= 0) earlyValues = forcedEarly != 0;
   for (uint32_t pass = 0; pass < VRDX_PASSES; ++pass) {

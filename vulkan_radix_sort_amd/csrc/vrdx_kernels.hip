@@ -851,11 +851,10 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   LdsBarrier();
   VRDX_STAMP(5);
 
-  // Key+value, late form: the values are fetched now and the key scatter covers their latency.
-  // The host picks the form per sort from measurements (RecordSort): early wins by 3-11 % up to about
-  // three rounds of tiles per CU (1024x32 at 2^24 pairs: 0.278 vs 0.311 ms), late by 1-3 % beyond
-  // (2^25: 0.574 vs 0.590 ms).  Issued right before the look-back the loads queue in front of its
-  // agent-scope status reads (6 -> 9 us, measured).
+  // Key+value, late form (measurements only, VRDX_KV_EARLY_VALUES=0): the values are fetched now and
+  // the key scatter covers their latency.  It used to win by 1-3 % for sorts of four and more rounds
+  // of tiles; on the final kernels the early form is as fast or faster everywhere.  Issued right
+  // before the look-back the loads queue in front of its agent-scope status reads (6 -> 9 us, measured).
   if constexpr (KV) {
     if (!a.earlyValues) LoadStriped<KPT>(valuesIn, loadBase, n, valid == TILE, 0u, val);
   }
