@@ -102,3 +102,13 @@ def test_bench_driver_cpu_backend_and_csv_format(tmp_path):
     assert [r[1] for r in rows] == ["1024", "1024", "4608", "4608", "8192", "8192"]
     assert [r[2] for r in rows] == ["keys", "kv"] * 3
     assert all(r[0] == "cpu" and float(r[3]) > 0 for r in rows)
+
+
+def test_storage_layout_invariants():
+    """vrdx_layout.h: status regions and tickets stay inside the reference's partition-histogram area
+    for every N up to the ceiling and every tile size, and the totals equal the oracle's (CPU only)."""
+    native = os.path.join(ROOT, "tests", "native")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
+    subprocess.run(["make", "-C", native, "layout_check"], check=True, capture_output=True)
+    r = subprocess.run([os.path.join(native, "layout_check")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and ", 0 failures" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
