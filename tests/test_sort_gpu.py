@@ -350,6 +350,25 @@ def test_constant_digit_passes_are_copied_correctly(torch_mod, sorter, oracle, n
         assert np.array_equal(gk, ek) and np.array_equal(gp, ep), name
 
 
+@pytest.mark.parametrize("n", [70_001, 9_000_001])
+def test_every_combination_of_constant_bytes(torch_mod, sorter, oracle, n):
+    """All 16 combinations of constant key bytes: whichever passes are skipped (and whichever single
+    pass copies, when the number of ranking passes is odd), the result must end in the caller's
+    buffers, sorted and stable.  n = 9 000 001 runs the two-sub-tile kernel for keys-only."""
+    rng = np.random.default_rng(1000 + n)
+    r = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+    iota = np.arange(n, dtype=np.uint32)
+    for mask in range(16):
+        keep = np.uint32(sum(0xFF << (8 * b) for b in range(4) if not (mask >> b) & 1))
+        const = np.uint32(sum((0x11 * (b + 3)) << (8 * b) for b in range(4) if (mask >> b) & 1))
+        k = (r & keep) | const
+        ek, ep, _ = oracle.sort(k, iota)
+        gk, _ = gpu_sort(torch_mod, sorter, k)
+        assert np.array_equal(gk, ek), mask
+        gk, gp = gpu_sort(torch_mod, sorter, k, iota)
+        assert np.array_equal(gk, ek) and np.array_equal(gp, ep), mask
+
+
 @pytest.mark.parametrize("seed", [1, 2])
 def test_full_size_2pow25_properties_and_golden_checksum(torch_mod, sorter, oracle, golden, seed):
     """BASELINE.json configs[1] and [2]: N = 2^25 uniform-random u32, keys-only and key+value."""
