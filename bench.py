@@ -11,9 +11,15 @@ the timed region holds exactly K sorts and nothing else (the reference likewise 
 and read-back: bench/vulkan_benchmark.cc:267-290,306-316, and uses fresh data per run:
 bench/bench.cc:83-84).
 
-With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) this is the batched
-many-arrays variant: every rank sorts its own independent arrays, there is no collective on the
-data path, and value = items sorted by all ranks / max-over-ranks time ("scaling": "weak").
+With --gpus N > 1 this is the batched many-arrays variant (BASELINE.json configs[4]): one rank per
+GPU, every rank sorts its own independent arrays through vulkan_radix_sort_amd.batched
+(HipShardExecutor: one VrdxSorter, one stream, one storage buffer per GPU), there is no collective
+on the data path -- only the 24-byte end-of-batch record all-gather over RCCL -- and value = items
+sorted by all ranks / max-over-ranks time ("scaling": "weak").  Either launched by
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / WORLD_SIZE in
+the environment) or plainly as `python bench.py --gpus N`, which then starts that launcher itself as
+a child process BEFORE anything touches a GPU.  The JSON's n_gpus is the number of ranks RCCL
+actually connected; a mismatch with --gpus is an error (exit code 2), never a silent N = 1.
 
 Rank 0 prints ONE JSON line.
 """
@@ -49,22 +55,16 @@ def random_u32(torch, n, seed, device):
     return torch.randint(-(1 << 31), 1 << 31, (n,), generator=g, device=device, dtype=torch.int64).to(torch.int32)
 
 
-def timed_sorts(torch, dist, sorter, n, steps, warmup, key_value, device, distributed):
-    """Returns (wall_seconds_for_K_steps_max_over_ranks, per-step gpu ms list of this rank)."""
-    stream = torch.cuda.current_stream().cuda_stream
-    req = sorter.key_value_storage_requirements(n) if key_value else sorter.storage_requirements(n)
-    storage = torch.empty(req.size, dtype=torch.uint8, device=device)
+def timed_sorts(torch, dist, executor, n, steps, warmup, key_value, device, distributed):
+    """Returns (wall_seconds_for_K_steps_max_over_ranks, per-step gpu ms list of this rank).
+    Every sort goes through the batched front end's per-GPU executor (one array per step and rank)."""
     total = warmup + 2 * steps   # warm-up | the K timed steps | K more, each bracketed by events
     seed0 = 1000 * (int(os.environ.get("RANK", "0")) + 1)
     keys = [random_u32(torch, n, seed0 + i, device) for i in range(total)]
     values = [random_u32(torch, n, seed0 + 500 + i, device) for i in range(total)] if key_value else None
 
     def one(i):
-        if key_value:
-            sorter.cmd_sort_key_value(stream, n, keys[i].data_ptr(), 0, values[i].data_ptr(), 0,
-                                      storage.data_ptr(), 0)
-        else:
-            sorter.cmd_sort(stream, n, keys[i].data_ptr(), 0, storage.data_ptr(), 0)
+        executor.enqueue([(keys[i], values[i] if key_value else None)])  # vrdxCmdSort[KeyValue]: never blocks
 
     for i in range(warmup):
         one(i)
@@ -94,14 +94,14 @@ def timed_sorts(torch, dist, sorter, n, steps, warmup, key_value, device, distri
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     per_step_ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]
-    status = sorter.read_status(stream, storage.data_ptr(), 0)
+    status = executor.finish()  # the sorter's sticky word: every sort above, not only the last one
     if status != 0:
         raise RuntimeError(f"device failure word {status}: look-back spin expired")
     # the last step's output must be sorted (cheap sanity check outside the timed region)
     k = keys[-1].view(torch.int32).to(torch.int64) & 0xFFFFFFFF
     if not bool((k[1:] >= k[:-1]).all()):
         raise RuntimeError("output not sorted")
-    del keys, values, storage
+    del keys, values
     torch.cuda.empty_cache()
     return elapsed, per_step_ms
 
@@ -179,22 +179,60 @@ def kernel_name(version, which):
     return "%s<%s, %s, %s, true>" % ("onesweep_pair_kernel" if m.group(3) else "onesweep_kernel", m.group(1), m.group(2), kv)
 
 
-def latest_pmc_traffic():
-    """HBM bytes per onesweep launch from the rocprofv3 PMC passes committed under profiles/
-    (collected offline: PMC cannot be read from inside this process)."""
+def latest_pmc_traffic(version):
+    """HBM bytes per onesweep launch from the rocprofv3 PMC passes committed under profiles/ (collected
+    offline by tools/profile_round.sh: counters cannot be read from inside this process).  Only a file
+    stamped with THIS library (same kernel source digest and tile choice) is believed; otherwise the
+    bench line says traffic = null rather than quote bytes measured on other kernels."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f)
+            pmc = json.load(f)
     except (OSError, ValueError):
         return None
+    if pmc.get("kernel_source_sha256") != kernel_source_digest() or pmc.get("library") != version:
+        return None
+    return pmc
+
+
+def kernel_source_digest():
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("vrdx_kernels.hip", "vrdx_kernels.h", "vrdx_layout.h", "vrdx_api.cpp"):
+        with open(os.path.join(ROOT, "vulkan_radix_sort_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks (torch.distributed.run) as a CHILD
+    process -- nothing in this process has touched a GPU yet, and nothing will -- and exit with the
+    child's code.  (Never exec from a process that holds a GPU context.)"""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()  # does not initialise the runtime
+    if have < args.gpus:
+        print(f"[bench] --gpus {args.gpus} but this node exposes {have} GPU(s)", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     import torch
     import torch.distributed as dist
     import vulkan_radix_sort_amd as vrdx
+    from vulkan_radix_sort_amd.batched import BatchedSorter, HipShardExecutor
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -207,18 +245,23 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl")
-    n_gpus = world if distributed else 1
-    if args.gpus != n_gpus and rank == 0:
-        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run; "
-              f"measuring {n_gpus} GPU(s)", file=sys.stderr)
+    n_gpus = dist.get_world_size() if distributed else 1   # the ranks RCCL actually connected
+    if args.gpus != n_gpus:
+        if rank == 0:
+            print(f"[bench] --gpus {args.gpus} but {n_gpus} rank(s) are running: refusing to report", file=sys.stderr)
+        sys.exit(2)
 
     n = 1 << args.log2n
-    sorter = vrdx.Sorter(local_rank)
+    executor = HipShardExecutor(local_rank)   # one VrdxSorter + stream + storage for this GPU
+    sorter = executor.sorter
+    batch = BatchedSorter(executor=executor)
 
-    wall_keys, steps_keys = timed_sorts(torch, dist, sorter, n, args.steps, args.warmup, False, device, distributed)
-    wall_kv, steps_kv = timed_sorts(torch, dist, sorter, n, args.steps, args.warmup, True, device, distributed)
+    wall_keys, steps_keys = timed_sorts(torch, dist, executor, n, args.steps, args.warmup, False, device, distributed)
+    wall_kv, steps_kv = timed_sorts(torch, dist, executor, n, args.steps, args.warmup, True, device, distributed)
     hist_ms, sweep_ms = stage_profile(torch, sorter, n, False, device)
     hist_kv_ms, sweep_kv_ms = stage_profile(torch, sorter, n, True, device)
+    # end-of-batch record of every rank (the batched variant's only collective; 24 bytes per rank)
+    records = batch.gather(0, int(wall_kv * 1e9), (args.warmup + 2 * args.steps) * n)
 
     def median(xs):
         s = sorted(xs)
@@ -232,8 +275,8 @@ def main():
     # 8 B/key (4 read + 4 write) x N   [key+value: 16 B/pair x N]
     sweep_bytes = 8.0 * n
     achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
-    pmc = latest_pmc_traffic()
     version = vrdx.version_string()
+    pmc = latest_pmc_traffic(version)
     roofline = {
         "bound": "hbm", "kernel": kernel_name(version, "keys"), "achieved": achieved, "peak": HBM_PEAK_GBPS,
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
@@ -260,7 +303,7 @@ def main():
                                f"(BASELINE.json configs[1]); key+value (configs[2]) under key_value",
                    "n": n, "arrays_per_step_per_gpu": 1,
                    "parallelism": "independent arrays, one per GPU, no data-path collective" if distributed else "single GPU",
-                   "tile": version},
+                   "tile": version, "ranks": [{"rank": r.rank, "status": r.status} for r in records]},
         "median_gpu_ms_per_sort": med_keys_ms, "median_gitems_per_s": n / (med_keys_ms * 1e-3) / 1e9,
         "key_value": {"value": value_kv, "unit": "GItems/s", "ms_per_step": wall_kv / args.steps * 1e3,
                       "median_gpu_ms_per_sort": med_kv_ms, "median_gitems_per_s": n / (med_kv_ms * 1e-3) / 1e9},
@@ -272,7 +315,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(n)
     if rank == 0:
         print(json.dumps(result))
-    sorter.destroy()
+    executor.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

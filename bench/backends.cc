@@ -84,6 +84,7 @@ class HipBenchmark : public BenchmarkBase {
     (void)hipStreamDestroy(stream_);
   }
   std::string LibraryVersion() const override { return vrdxHipVersionString(); }
+  bool Healthy() override { return vrdxHipReadSorterStatus(sorter_, (VkCommandBuffer)stream_) == 0; }
 
   Results Sort(const std::vector<uint32_t>& keys) override {
     const uint32_t n = static_cast<uint32_t>(keys.size());

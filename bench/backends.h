@@ -23,6 +23,8 @@ class BenchmarkBase {
   };
   virtual ~BenchmarkBase() = default;
   virtual std::string LibraryVersion() const { return ""; }
+  // false if any sort since the last call failed on the device (hip: vrdxHipReadSorterStatus)
+  virtual bool Healthy() { return true; }
   virtual Results Sort(const std::vector<uint32_t>& keys) = 0;
   virtual Results SortKeyValue(const std::vector<uint32_t>& keys, const std::vector<uint32_t>& values) = 0;
 };
@@ -58,5 +60,8 @@ class DataGenerator {
 // when the driver was built with the comparator (bench/rocprim_backend.hip).
 std::unique_ptr<BenchmarkBase> CreateBenchmark(const std::string& type);
 std::unique_ptr<BenchmarkBase> CreateRocprimBenchmark();  // nullptr when not compiled in
+
+// bench hip --devices G: returns the process exit code (batched.cc).
+int RunBatched(int devices, int arrays, int log2n, bool verify);
 
 #endif  // VRDX_BENCH_BACKENDS_H

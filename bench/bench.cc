@@ -8,6 +8,10 @@
 //     --no-verify skip the one-shot correctness check against the cpu backend at the first point
 //     --points K  number of sweep points between N = 2^18 and 2^25 (default 128, like the reference)
 //     --min-log2n A / --max-log2n B   other sweep ends (the reference hard-codes 18 and 25)
+//   bench hip --devices G [--arrays A] [--log2n L]
+//     the batched many-arrays variant: A independent key+value arrays of 2^L elements, array i on
+//     GPU i mod G, one VrdxSorter + stream + storage per GPU, all enqueued from this one host thread;
+//     the per-GPU {status, elapsed} records are exchanged with ncclAllGather (RCCL) -- see batched.cc
 //
 // Per (N, keys|kv): 1 warm-up + 10 timed runs on FRESH data each run, median.  CSV columns are the
 // reference's seven (backend,n,sort,gpu_ms,cpu_ms,gpu_gitems_s,cpu_gitems_s) followed by
@@ -34,60 +38,84 @@
 
 namespace {
 
-constexpr int kWarmupRuns = 1;                  // bench/bench.cc:15
-constexpr int kTimedRuns = 10;                  // :16
-uint32_t kNMin = 1u << 18;                      // :17
-uint32_t kNMax = 1u << 25;                      // :18
+// protocol constants of the reference's driver (bench/bench.cc:15-20)
+constexpr int kWarmupRuns = 1;
+constexpr int kTimedRuns = 10;
+uint32_t kNMin = 1u << 18;
+uint32_t kNMax = 1u << 25;
 
-double toMs(uint64_t ns) { return static_cast<double>(ns) / 1e6; }
-double toGItemsS(uint32_t n, uint64_t ns) { return ns ? (static_cast<double>(n) / 1e9) / (static_cast<double>(ns) / 1e9) : 0.0; }
+// One (N, sort) line of the sweep: the five nanosecond series of its timed runs, reduced on demand.
+class Series {
+ public:
+  enum Column { kDevice, kWall, kUpsweep, kSpine, kDownsweep, kColumns };
+  void Add(const BenchmarkBase::Results& r) {
+    const uint64_t sample[kColumns] = {r.total_time, r.cpu_time, r.upsweep_ns, r.spine_ns, r.downsweep_ns};
+    for (int c = 0; c < kColumns; ++c) ns_[c].push_back(sample[c]);
+  }
+  // upper median, like the reference's (element size/2 of the sorted series)
+  double MedianMs(Column c) const {
+    std::vector<uint64_t> sorted(ns_[c]);
+    if (sorted.empty()) return 0.0;
+    std::sort(sorted.begin(), sorted.end());
+    return 1e-6 * static_cast<double>(sorted[sorted.size() / 2]);
+  }
 
-uint64_t median(std::vector<uint64_t>& v) {
-  auto mid = static_cast<std::ptrdiff_t>(v.size() / 2);
-  std::nth_element(v.begin(), v.begin() + mid, v.end());
-  return v[static_cast<size_t>(mid)];
-}
-
-struct Row {
-  uint32_t n;
-  std::string sort;
-  double gpu_ms, cpu_ms, gpu_gitems_s, cpu_gitems_s, upsweep_ms, spine_ms, downsweep_ms;
+ private:
+  std::vector<uint64_t> ns_[kColumns];
 };
 
-bool checkCorrectness(BenchmarkBase* bench, BenchmarkBase* cpu, uint32_t n, DataGenerator& gen) {
-  auto data = gen.Generate(n);
-  auto r0 = bench->Sort(data.keys);
-  auto r1 = cpu->Sort(data.keys);
-  for (uint32_t i = 0; i < n; ++i)
-    if (r0.keys[i] != r1.keys[i]) {
-      std::cerr << "Sort correctness failed at index " << i << std::endl;
+struct Line {
+  uint32_t n;
+  const char* sort;  // "keys" | "kv"
+  Series series;
+  double Ms(Series::Column c) const { return series.MedianMs(c); }
+  double GItemsPerSecond(Series::Column c) const {
+    const double ms = Ms(c);
+    return ms > 0.0 ? static_cast<double>(n) / (ms * 1e6) : 0.0;
+  }
+  double AlgorithmicGBps() const {  // 36 B/key, 68 B/pair
+    const double ms = Ms(Series::kDevice);
+    return ms > 0.0 ? (std::strcmp(sort, "keys") == 0 ? 36.0 : 68.0) * n / (ms * 1e6) : 0.0;
+  }
+};
+
+// The reference's predicate (bench/bench.cc:41-64): the backend under test and the cpu backend agree on
+// every key, and on every (key, value) pair of the stable key+value sort.
+bool AgreesWithCpu(BenchmarkBase& tested, BenchmarkBase& cpu, uint32_t n, DataGenerator& gen) {
+  const SortData input = gen.Generate(n);
+  const auto firstDifference = [](const std::vector<uint32_t>& a, const std::vector<uint32_t>& b) {
+    return static_cast<size_t>(std::mismatch(a.begin(), a.end(), b.begin(), b.end()).first - a.begin());
+  };
+  {
+    const auto got = tested.Sort(input.keys), want = cpu.Sort(input.keys);
+    const size_t at = firstDifference(got.keys, want.keys);
+    if (at != n || got.keys.size() != want.keys.size()) {
+      std::cerr << "keys-only sort differs from the cpu backend at element " << at << " of " << n << std::endl;
       return false;
     }
-  auto r2 = bench->SortKeyValue(data.keys, data.values);
-  auto r3 = cpu->SortKeyValue(data.keys, data.values);
-  for (uint32_t i = 0; i < n; ++i)
-    if (r2.keys[i] != r3.keys[i] || r2.values[i] != r3.values[i]) {
-      std::cerr << "SortKeyValue correctness failed at index " << i << std::endl;
+  }
+  {
+    const auto got = tested.SortKeyValue(input.keys, input.values), want = cpu.SortKeyValue(input.keys, input.values);
+    const size_t at = std::min(firstDifference(got.keys, want.keys), firstDifference(got.values, want.values));
+    if (at != n || got.keys.size() != want.keys.size() || got.values.size() != want.values.size()) {
+      std::cerr << "key+value sort differs from the cpu backend at element " << at << " of " << n << std::endl;
       return false;
     }
+  }
   std::cout << "Correctness check passed (N=" << n << ")" << std::endl;
   return true;
 }
 
-Row measure(BenchmarkBase* bench, uint32_t n, const std::string& sort, DataGenerator& gen) {
-  auto once = [&](const SortData& d) { return sort == "keys" ? bench->Sort(d.keys) : bench->SortKeyValue(d.keys, d.values); };
-  for (int i = 0; i < kWarmupRuns; ++i) once(gen.Generate(n));
-  std::vector<uint64_t> gpu, cpu, up, sp, dn;
-  for (int i = 0; i < kTimedRuns; ++i) {
-    auto r = once(gen.Generate(n));
-    gpu.push_back(r.total_time);
-    cpu.push_back(r.cpu_time);
-    up.push_back(r.upsweep_ns);
-    sp.push_back(r.spine_ns);
-    dn.push_back(r.downsweep_ns);
+// kWarmupRuns + kTimedRuns sorts, every one on freshly generated data (bench/bench.cc:66-112).
+Line Measure(BenchmarkBase& bench, uint32_t n, const char* sort, DataGenerator& gen) {
+  Line line{n, sort, {}};
+  const bool keysOnly = std::strcmp(sort, "keys") == 0;
+  for (int run = -kWarmupRuns; run < kTimedRuns; ++run) {
+    const SortData input = gen.Generate(n);
+    const BenchmarkBase::Results r = keysOnly ? bench.Sort(input.keys) : bench.SortKeyValue(input.keys, input.values);
+    if (run >= 0) line.series.Add(r);
   }
-  const uint64_t g = median(gpu), c = median(cpu);
-  return Row{n, sort, toMs(g), toMs(c), toGItemsS(n, g), toGItemsS(n, c), toMs(median(up)), toMs(median(sp)), toMs(median(dn))};
+  return line;
 }
 
 }  // namespace
@@ -96,6 +124,7 @@ int main(int argc, char** argv) {
   std::string type, output = "results.csv";
   bool verify = true;
   int points = 128;  // bench/bench.cc:19 kNCount
+  int devices = 0, arrays = 8, batchLog2n = 25;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     if (a == "-o" || a == "--output") {
@@ -108,6 +137,12 @@ int main(int argc, char** argv) {
       if (++i < argc) kNMin = 1u << std::min(29, std::max(0, std::atoi(argv[i])));
     } else if (a == "--max-log2n") {
       if (++i < argc) kNMax = 1u << std::min(29, std::max(0, std::atoi(argv[i])));
+    } else if (a == "--devices") {
+      if (++i < argc) devices = std::max(1, std::atoi(argv[i]));
+    } else if (a == "--arrays") {
+      if (++i < argc) arrays = std::max(1, std::atoi(argv[i]));
+    } else if (a == "--log2n") {
+      if (++i < argc) batchLog2n = std::min(29, std::max(10, std::atoi(argv[i])));
     } else if (a == "-h" || a == "--help") {
       type.clear();
       break;
@@ -116,9 +151,18 @@ int main(int argc, char** argv) {
     }
   }
   if (type.empty()) {
-    std::cout << "usage: bench <hip|cpu|rocprim> [-o results.csv] [--no-verify] [--points K] [--min-log2n A] [--max-log2n B]"
+    std::cout << "usage: bench <hip|cpu|rocprim> [-o results.csv] [--no-verify] [--points K] [--min-log2n A] [--max-log2n B]\n"
+                 "       bench hip --devices G [--arrays A] [--log2n L] [--no-verify]   (batched: A key+value arrays of 2^L over G GPUs)"
               << std::endl;
     return 0;
+  }
+
+  if (devices > 0) {  // the batched many-arrays variant (BASELINE.json configs[4]): see batched.cc
+    if (type != "hip") {
+      std::cerr << "--devices needs the hip backend" << std::endl;
+      return 1;
+    }
+    return RunBatched(devices, arrays, batchLog2n, verify);
   }
 
   std::unique_ptr<BenchmarkBase> bench = CreateBenchmark(type);
@@ -130,33 +174,36 @@ int main(int argc, char** argv) {
   DataGenerator gen;  // random_device seeded, like the reference (bench/bench.cc:158)
 
   const uint32_t step = (kNMax - kNMin) / static_cast<uint32_t>(points - 1);  // :20
-  std::vector<Row> rows;
+  std::vector<Line> lines;
   for (int i = 0; i < points; ++i) {
     const uint32_t n = i == points - 1 ? kNMax : kNMin + step * static_cast<uint32_t>(i);
-    if (i == 0 && verify && type != "cpu" && !checkCorrectness(bench.get(), cpu.get(), n, gen)) return 1;
+    if (i == 0 && verify && type != "cpu" && !AgreesWithCpu(*bench, *cpu, n, gen)) return 1;
     for (const char* sort : {"keys", "kv"}) {
-      Row r = measure(bench.get(), n, sort, gen);
-      std::cout << std::fixed << std::setprecision(3) << type << " n=" << r.n << " " << r.sort << "  gpu " << r.gpu_ms << " ms ("
-                << r.gpu_gitems_s << " GItems/s)  wall " << r.cpu_ms << " ms";
-      const double stages = r.upsweep_ms + r.spine_ms + r.downsweep_ms;
-      if (stages > 0)
-        std::cout << "  [up " << 100.0 * r.upsweep_ms / stages << "% sp " << 100.0 * r.spine_ms / stages << "% dn "
-                  << 100.0 * r.downsweep_ms / stages << "%]";
+      lines.push_back(Measure(*bench, n, sort, gen));
+      const Line& l = lines.back();
+      std::cout << std::fixed << std::setprecision(3) << type << " n=" << l.n << " " << l.sort << "  gpu "
+                << l.Ms(Series::kDevice) << " ms (" << l.GItemsPerSecond(Series::kDevice) << " GItems/s)  wall "
+                << l.Ms(Series::kWall) << " ms";
+      const double up = l.Ms(Series::kUpsweep), sp = l.Ms(Series::kSpine), dn = l.Ms(Series::kDownsweep);
+      if (up + sp + dn > 0)
+        std::cout << "  [up " << 100.0 * up / (up + sp + dn) << "% sp " << 100.0 * sp / (up + sp + dn) << "% dn "
+                  << 100.0 * dn / (up + sp + dn) << "%]";
       std::cout << std::endl;
-      rows.push_back(r);
     }
+  }
+  if (!bench->Healthy()) {
+    std::cerr << "the device reported a failed sort (bounded look-back spin expired)" << std::endl;
+    return 1;
   }
 
   std::ofstream csv(output);
   const std::string version = bench->LibraryVersion();
   if (!version.empty()) csv << "# version: " << version << "\n";  // bench/bench.cc:197-198, read by tools/plot.py:53-57
   csv << "backend,n,sort,gpu_ms,cpu_ms,gpu_gitems_s,cpu_gitems_s,achieved_GBps,hbm_fraction\n";
-  for (const Row& r : rows) {
-    const double bytes = (r.sort == "keys" ? 36.0 : 68.0) * r.n;
-    const double gbps = r.gpu_ms > 0 ? bytes / (r.gpu_ms * 1e-3) / 1e9 : 0.0;
-    csv << type << "," << r.n << "," << r.sort << "," << std::setprecision(6) << r.gpu_ms << "," << r.cpu_ms << "," << r.gpu_gitems_s
-        << "," << r.cpu_gitems_s << "," << gbps << "," << gbps / 8000.0 << "\n";
-  }
+  for (const Line& l : lines)
+    csv << type << "," << l.n << "," << l.sort << "," << std::setprecision(6) << l.Ms(Series::kDevice) << "," << l.Ms(Series::kWall)
+        << "," << l.GItemsPerSecond(Series::kDevice) << "," << l.GItemsPerSecond(Series::kWall) << "," << l.AlgorithmicGBps() << ","
+        << l.AlgorithmicGBps() / 8000.0 << "\n";
   std::cout << "wrote " << output << std::endl;
   return 0;
 }

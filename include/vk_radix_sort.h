@@ -181,13 +181,21 @@ void vrdxHipDestroyQueryPool(VkQueryPool queryPool);
 VkResult vrdxHipGetQueryPoolResults(VkQueryPool queryPool, uint32_t firstQuery, uint32_t queryCount,
                                     uint64_t* pData);
 
-/* Device-side failure word of the last sorts that used this storage: 0 = ok.  A non-zero value
- * means a bounded look-back spin expired (the GPU never hangs; the output is then unspecified).
- * Synchronises the given stream.  Diagnostic only. */
+/* Device-side failure word of the LAST sort recorded with this storage (recording a sort clears the
+ * word): 0 = ok.  A non-zero value means a bounded look-back spin expired (the GPU never hangs; the
+ * output is then unspecified).  Synchronises the given stream.  Diagnostic only. */
 uint32_t vrdxHipReadStatus(VkCommandBuffer commandBuffer, VkBuffer storageBuffer,
                            VkDeviceSize storageOffset);
 
-/* Library build info: "vrdx-hip <version> gfx950 tile=<keys per tile>". */
+/* The same diagnosis for EVERY sort recorded with this sorter since the previous call (or since
+ * vrdxCreateSorter), whatever storage they used: the OR of their failure bits, kept in a device
+ * word the sorter owns; reading it clears it.  This is what a caller that runs many sorts through
+ * one storage buffer checks once at the end.  Synchronises the given stream (which must belong to
+ * the sorter's device and be ordered after the sorts in question). */
+uint32_t vrdxHipReadSorterStatus(VrdxSorter sorter, VkCommandBuffer commandBuffer);
+
+/* Library build info: "vrdx-hip <version> gfx950 tiles at 2^25: keys=<threads>x<keys per thread>[x<sub-tiles>]
+ * key-value=... (size-adaptive | forced)". */
 const char* vrdxHipVersionString(void);
 
 #ifdef __cplusplus

@@ -526,12 +526,143 @@ def test_small_sort_boundary_sizes(torch_mod, sorter, oracle, n):
     check_against_oracle(torch_mod, sorter, oracle, k, iota, count=max(n - 3, 0), indirect=True, max_count=n)
 
 
-@pytest.mark.parametrize("config", ["1024x16", "512x32", "1024x8", "512x16", "512x24", "1024x32", "1024x32x2", "512x32x2"])
-def test_other_tile_configs(torch_mod, oracle, config):
-    """Every compiled tile geometry is parity-clean, not only the default one."""
+ALL_TILE_CONFIGS = ["1024x8", "1024x16", "1024x32", "1024x32x2"]  # == kTileConfigs in vrdx_kernels.hip
+
+
+def _selftest(args, **env):
     exe = os.path.join(ROOT, "tests", "native", "vrdx_selftest")
     if not os.path.exists(exe):
         subprocess.run(["make", "-C", os.path.dirname(exe)], check=True)
-    env = dict(os.environ, VRDX_TILE_CONFIG=config)
-    r = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return subprocess.run([exe] + args, capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+
+
+@pytest.mark.parametrize("config", ALL_TILE_CONFIGS)
+def test_other_tile_configs(torch_mod, oracle, config):
+    """Every compiled tile geometry is parity-clean at every size, not only where it is selected."""
+    r = _selftest(["quick"], VRDX_TILE_CONFIG=config)
+    assert r.returncode == 0 and ", 0 failures" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "keys=" + config in r.stdout
+
+
+def test_version_string_lists_only_compiled_configs():
+    """An unknown (e.g. pruned) geometry is refused loudly and the size-adaptive selection is used."""
+    r = _selftest(["quick"], VRDX_TILE_CONFIG="512x16")
+    assert r.returncode == 0 and "unknown VRDX_TILE_CONFIG" in r.stderr and "(size-adaptive)" in r.stdout
+
+
+# ---- the ballot ranking (VRDX_RANK=ballot): the form that uses only architecturally defined behaviour --------
+# vrdxCreateSorter selects it when the device check of the one-atomic ranking fails; it never does on an
+# MI355X, so these tests force it.  Every <..., ATOMIC_RANK = false> instantiation is reached: the single-
+# workgroup kernels (small sizes), 1024x8 / 1024x16 / 1024x32 keys-only and key+value, and the two-sub-tile
+# kernel through its forced geometry.
+
+@pytest.mark.parametrize("config", [None] + ALL_TILE_CONFIGS)
+def test_ballot_ranking_native_battery(config):
+    env = {"VRDX_RANK": "ballot"}
+    if config is not None:
+        env["VRDX_TILE_CONFIG"] = config
+    r = _selftest(["quick"], **env)
+    assert r.returncode == 0 and ", 0 failures" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.fixture(scope="module")
+def ballot_sorter(torch_mod):
+    import vulkan_radix_sort_amd as vrdx
+    old = os.environ.get("VRDX_RANK")
+    os.environ["VRDX_RANK"] = "ballot"  # read by vrdxCreateSorter
+    try:
+        s = vrdx.Sorter()
+    finally:
+        if old is None:
+            del os.environ["VRDX_RANK"]
+        else:
+            os.environ["VRDX_RANK"] = old
+    yield s
+    s.destroy()
+
+
+@pytest.mark.parametrize("n", [1, 255, 4096, 4097, 16383, 16384, 16385])
+def test_ballot_ranking_small_sort_boundary_sizes(torch_mod, ballot_sorter, oracle, n):
+    k, _ = oracle.generate(5, n, 8)
+    iota = np.arange(n, dtype=np.uint32)
+    check_against_oracle(torch_mod, ballot_sorter, oracle, k)
+    check_against_oracle(torch_mod, ballot_sorter, oracle, k, iota)
+    check_against_oracle(torch_mod, ballot_sorter, oracle, k, iota, count=max(n - 3, 0), indirect=True, max_count=n)
+
+
+@pytest.mark.parametrize("n", [int(0.10 * (1 << 23)) + 12345, int(0.40 * (1 << 23)) + 12345, (1 << 23) + 1, (1 << 24) + 1])
+def test_ballot_ranking_every_size_regime(torch_mod, ballot_sorter, oracle, n):
+    """1024x8, 1024x16, 1024x32 and (where the atomic form would take the two-sub-tile kernel) 1024x32 again."""
+    k, _ = oracle.generate(3, n, 32)
+    iota = np.arange(n, dtype=np.uint32)
+    ek, ep, _ = oracle.sort(k, iota)
+    gk, _ = gpu_sort(torch_mod, ballot_sorter, k)
+    assert np.array_equal(gk, ek)
+    gk, gp = gpu_sort(torch_mod, ballot_sorter, k, iota)
+    assert np.array_equal(gk, ek) and np.array_equal(gp, ep)
+
+
+# ---- a7: the fused histogram table itself (not only sorts that come out right) ---------------------------------
+
+def _histogram_table_after_sort(torch, sorter, keys, count=None, indirect=False, values=None):
+    n_buf = len(keys)
+    n = n_buf if count is None else count
+    dk = _u32_to_dev(torch, keys)
+    dv = _u32_to_dev(torch, values) if values is not None else None
+    req = sorter.key_value_storage_requirements(n_buf) if values is not None else sorter.storage_requirements(n_buf)
+    storage = torch.full((req.size,), 0xA5, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    if indirect:
+        dcount = _u32_to_dev(torch, np.array([n, 0, 0, 0], dtype=np.uint32))
+        sorter.cmd_sort_indirect(stream, n_buf, dcount.data_ptr(), 0, dk.data_ptr(), 0, storage.data_ptr(), 0)
+    elif values is not None:
+        sorter.cmd_sort_key_value(stream, n, dk.data_ptr(), 0, dv.data_ptr(), 0, storage.data_ptr(), 0)
+    else:
+        sorter.cmd_sort(stream, n, dk.data_ptr(), 0, storage.data_ptr(), 0)
+    torch.cuda.synchronize()
+    # uint32[4][256] at byte 16 of the storage: where the reference keeps globalHistogram
+    # (src/vk_radix_sort.h.in:405-406); raw counts of the valid keys here (DESIGN.md section 3)
+    return storage[16:16 + 4096].cpu().numpy().view(np.uint32).reshape(4, 256), _to_u32(dk)
+
+
+@pytest.mark.parametrize("n", [16385, 100_003, (1 << 20) + 7, 5_000_011, (1 << 24) + 3])
+def test_histogram_table_matches_oracle_digit_counts(torch_mod, sorter, oracle, n):
+    """upsweep on its own: the 4 x 256 table the fused histogram kernel leaves in the storage
+    equals the oracle's digit counts of the n valid keys -- uniform, all-equal (every pass trivial: the table
+    is the only thing those sorts compute), few-distinct, and with a device-side count below the bound."""
+    k, v = oracle.generate(9, n, 32)
+    table, _ = _histogram_table_after_sort(torch_mod, sorter, k)
+    assert np.array_equal(table, oracle.digit_counts(k))
+    table, _ = _histogram_table_after_sort(torch_mod, sorter, k, values=v)
+    assert np.array_equal(table, oracle.digit_counts(k))
+    equal = np.full(n, 0x12345678, np.uint32)
+    table, gk = _histogram_table_after_sort(torch_mod, sorter, equal)
+    assert np.array_equal(table, oracle.digit_counts(equal)) and np.array_equal(gk, equal)
+    few = np.array([3, 0xFFFFFFFF, 0x00010000, 0x7F000000], np.uint32)[np.random.default_rng(n).integers(0, 4, n)]
+    table, _ = _histogram_table_after_sort(torch_mod, sorter, few)
+    assert np.array_equal(table, oracle.digit_counts(few))
+    count = n - n // 3
+    table, gk = _histogram_table_after_sort(torch_mod, sorter, k, count=count, indirect=True)
+    assert np.array_equal(table, oracle.digit_counts(k, count))
+    assert np.array_equal(gk[:count], oracle.sort(k, count=count)[0][:count]) and np.array_equal(gk[count:], k[count:])
+
+
+def test_sorter_status_is_sticky_across_sorts_sharing_one_storage(torch_mod, sorter, oracle):
+    """vrdxHipReadSorterStatus: one word for every sort recorded with the sorter, read (and cleared) once at the
+    end -- what a batch through ONE storage buffer checks, since each recorded sort clears the storage's own word."""
+    torch = torch_mod
+    stream = torch.cuda.current_stream().cuda_stream
+    assert sorter.read_sorter_status(stream) == 0
+    n = 300_000
+    req = sorter.key_value_storage_requirements(n)
+    storage = torch.full((req.size,), 0xA5, dtype=torch.uint8, device="cuda")
+    expected, buffers = [], []
+    for seed in range(4):
+        k, v = oracle.generate(20 + seed, n - 1000 * seed, 32)
+        dk, dv = _u32_to_dev(torch, k), _u32_to_dev(torch, v)
+        sorter.cmd_sort_key_value(stream, len(k), dk.data_ptr(), 0, dv.data_ptr(), 0, storage.data_ptr(), 0)
+        buffers.append((dk, dv))
+        expected.append(oracle.sort(k, v))
+    assert sorter.read_sorter_status(stream) == 0
+    for (dk, dv), (ek, ev, _) in zip(buffers, expected):
+        assert np.array_equal(_to_u32(dk), ek) and np.array_equal(_to_u32(dv), ev)

@@ -11,8 +11,16 @@ PATTERN=${4:-uniform}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 d=/tmp/vrdx_trace
 mkdir -p $d "$ROOT/gpurun_out"
-(cd $ROOT/vulkan_radix_sort_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC \
-    -DVRDX_TRACE ${EXTRA_FLAGS:-} -x hip vrdx_kernels.hip vrdx_api.cpp -shared -o $d/libvrdx_hip.so) || exit 1
+# A library cross-compiled beforehand (make -C vulkan_radix_sort_amd/csrc trace -> build/trace/) saves
+# the compile time on the GPU box; it must be newer than the sources.
+pre=$ROOT/build/trace/libvrdx_hip.so
+if [ -z "${EXTRA_FLAGS:-}" ] && [ -f $pre ] && [ $pre -nt $ROOT/vulkan_radix_sort_amd/csrc/vrdx_kernels.hip ] \
+    && [ $pre -nt $ROOT/vulkan_radix_sort_amd/csrc/vrdx_api.cpp ]; then
+  cp $pre $d/libvrdx_hip.so
+else
+  (cd $ROOT/vulkan_radix_sort_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC \
+      -DVRDX_TRACE ${EXTRA_FLAGS:-} -x hip vrdx_kernels.hip vrdx_api.cpp -shared -o $d/libvrdx_hip.so) || exit 1
+fi
 LD_LIBRARY_PATH=$d VRDX_TILE_CONFIG=$CONFIG VRDX_TRACE_FILE=$d/trace.bin timeout 120 \
     $ROOT/tests/native/vrdx_selftest trace $LOG2N $KV $PATTERN || exit 1
 {

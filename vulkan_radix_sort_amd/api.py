@@ -49,6 +49,7 @@ EXPORTED_SYMBOLS = (
     "vrdxHipDestroyQueryPool",
     "vrdxHipGetQueryPoolResults",
     "vrdxHipReadStatus",
+    "vrdxHipReadSorterStatus",
     "vrdxHipVersionString",
 )
 
@@ -115,6 +116,8 @@ def load_library() -> ctypes.CDLL:
     lib.vrdxHipGetQueryPoolResults.argtypes = [vp, u32, u32, ctypes.POINTER(u64)]
     lib.vrdxHipReadStatus.restype = u32
     lib.vrdxHipReadStatus.argtypes = [vp, vp, u64]
+    lib.vrdxHipReadSorterStatus.restype = u32
+    lib.vrdxHipReadSorterStatus.argtypes = [vp, vp]
     lib.vrdxHipVersionString.restype = ctypes.c_char_p
     lib.vrdxHipVersionString.argtypes = []
     _LIB = lib
@@ -238,6 +241,11 @@ class Sorter:
     # -- diagnostics ------------------------------------------------------------------------
     def read_status(self, command_buffer, storage, storage_offset=0) -> int:
         return int(self._lib.vrdxHipReadStatus(_handle(command_buffer), _handle(storage), storage_offset))
+
+    def read_sorter_status(self, command_buffer) -> int:
+        """OR of the failure bits of every sort recorded with this sorter since the previous call,
+        whatever storage they used (``vrdxHipReadSorterStatus``); synchronises the stream."""
+        return int(self._lib.vrdxHipReadSorterStatus(self.handle, _handle(command_buffer)))
 
 
 def _pool(p) -> Optional[int]:

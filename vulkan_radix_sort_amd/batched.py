@@ -35,7 +35,13 @@ class BatchRecord:
 
 
 class HipShardExecutor:
-    """Sorts this rank's arrays on its GPU through the C-ABI (libvrdx_hip.so).  No fallback."""
+    """Sorts this rank's arrays on its GPU through the C-ABI (libvrdx_hip.so).  No fallback.
+
+    One ``VrdxSorter``, one stream (torch's current stream of that device) and one storage buffer per
+    executor, i.e. per GPU.  ``enqueue`` never blocks the host -- like the
+    ``vrdxCmdSort*`` calls it wraps -- and ``finish`` synchronises once and returns the sorter's sticky
+    failure word (``vrdxHipReadSorterStatus``): the OR over EVERY sort enqueued since the last
+    ``finish``, although they all share one storage buffer whose own failure word each of them clears."""
 
     def __init__(self, device: Optional[int] = None):
         import torch
@@ -43,29 +49,40 @@ class HipShardExecutor:
         if not torch.cuda.is_available():
             raise RuntimeError("HipShardExecutor needs a GPU (there is no CPU fallback)")
         self.torch = torch
-        self.device = torch.cuda.current_device() if device is None else device
+        self.device = torch.cuda.current_device() if device is None else int(device)
         self.sorter = Sorter(self.device)
         self._storage = None
 
     def _storage_for(self, nbytes: int):
         if self._storage is None or self._storage.numel() < nbytes:
+            # (sorts still in flight use the old buffer: stream order keeps it alive long enough,
+            # torch's caching allocator does not hand it out again before they have run)
             self._storage = self.torch.empty(nbytes, dtype=self.torch.uint8, device=f"cuda:{self.device}")
         return self._storage
 
-    def __call__(self, arrays: Sequence[tuple]) -> int:
+    def _check(self, t, what):
+        if t.dtype.itemsize != 4 or t.dim() != 1 or not t.is_contiguous():
+            raise TypeError(f"{what}: expected a contiguous 1-d tensor of 4-byte elements, got {t.dtype} {tuple(t.shape)}")
+        if not t.is_cuda or t.device.index != self.device:
+            raise ValueError(f"{what}: lives on {t.device}, this executor sorts on cuda:{self.device}")
+
+    def enqueue(self, arrays: Sequence[tuple]) -> int:
         """arrays: (keys_tensor, values_tensor_or_None) pairs resident on this GPU (int32/uint32
-        storage, sorted in place as uint32).  Enqueues everything, then synchronises once.
-        Returns the OR of the device failure words."""
+        storage, sorted in place as uint32).  Returns the number of elements enqueued."""
         torch = self.torch
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        status = 0
-        need = 0
+        need, items = 16, 0
         for keys, values in arrays:
+            self._check(keys, "keys")
+            if values is not None:
+                self._check(values, "values")
+                if values.numel() != keys.numel():
+                    raise ValueError("keys and values differ in length")
             n = keys.numel()
             req = (self.sorter.key_value_storage_requirements(n) if values is not None
                    else self.sorter.storage_requirements(n))
             need = max(need, req.size)
-        storage = self._storage_for(max(need, 16))
+        storage = self._storage_for(need)
         for keys, values in arrays:
             n = keys.numel()
             if values is None:
@@ -73,10 +90,20 @@ class HipShardExecutor:
             else:
                 self.sorter.cmd_sort_key_value(stream, n, keys.data_ptr(), 0, values.data_ptr(), 0,
                                                storage.data_ptr(), 0)
-        torch.cuda.synchronize(self.device)
-        if arrays:
-            status |= self.sorter.read_status(stream, storage.data_ptr(), 0)
-        return status
+            items += n
+        return items
+
+    def finish(self) -> int:
+        """Waits for everything enqueued; returns the OR of the failure bits of all of it (0 = ok)."""
+        stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        return self.sorter.read_sorter_status(stream)
+
+    def __call__(self, arrays: Sequence[tuple]) -> int:
+        self.enqueue(arrays)
+        return self.finish()
+
+    def close(self):
+        self.sorter.destroy()
 
 
 class BatchedSorter:
@@ -102,14 +129,21 @@ class BatchedSorter:
         status = int(self.executor(arrays))
         elapsed = time.perf_counter_ns() - t0
         items = int(sum(int(k.numel()) if hasattr(k, "numel") else len(k) for k, _ in arrays))
-        mine = torch.tensor([status, elapsed, items], dtype=torch.int64)
+        return self.gather(status, elapsed, items)
+
+    def gather(self, status: int, elapsed_ns: int, items: int) -> List[BatchRecord]:
+        """The only collective of the batched variant: one 24-byte record per rank, all-gathered (RCCL
+        over xGMI with the nccl backend); it is also the cross-GPU completion barrier."""
+        import torch
+        mine = torch.tensor([status, elapsed_ns, items], dtype=torch.int64)
         if not self.distributed:
-            return [BatchRecord(0, status, elapsed, items)]
-        backend = self.dist.get_backend(self.group)
-        if backend == "nccl":
-            mine = mine.cuda()
+            return [BatchRecord(0, status, elapsed_ns, items)]
+        if self.dist.get_backend(self.group) == "nccl":
+            # RCCL wants the tensor on THIS rank's GPU: the executor's device, not whatever is current
+            device = getattr(self.executor, "device", None)
+            mine = mine.to(f"cuda:{device}" if device is not None else "cuda")
         gathered = [torch.empty_like(mine) for _ in range(self.world_size)]
-        self.dist.all_gather(gathered, mine, group=self.group)  # the only collective: 24 bytes per rank
+        self.dist.all_gather(gathered, mine, group=self.group)
         return [BatchRecord(r, int(g[0]), int(g[1]), int(g[2])) for r, g in enumerate(gathered)]
 
     @staticmethod

@@ -25,6 +25,10 @@ struct VrdxSorter_T {
   int computeUnits = 0;
   // (tile geometry is chosen per sort from the element count, see ConfigIndex)
   bool atomicRank = false;  // LDS returning atomics proven lane-ordered on this device
+  // One device word owned by the sorter: kernels OR their failure bit into it and nothing but
+  // vrdxHipReadSorterStatus clears it, so a caller that reuses ONE storage buffer for many sorts (each
+  // of which clears the storage's own failure word) still learns about a failure in any of them.
+  uint32_t* stickyStatus = nullptr;
   // reference: VrdxSorter_T::minStorageBufferOffsetAlignment (src/vk_radix_sort.h.in:134)
   uint32_t minStorageBufferOffsetAlignment = VRDX_STORAGE_ALIGN;
 };
@@ -77,7 +81,7 @@ int ForcedConfigIndex() {
 //    just past the round boundaries; on the final kernels they no longer do);
 //  * the two-sub-tile kernel (65536 keys, keys-only) halves the rounds again: best when f is in
 //    (1, 2], just below 4 or 6.
-enum : int { kCfg1024x16 = 1, kCfg1024x8 = 3, kCfg1024x32 = 7, kCfg1024x32x2 = 8 };
+enum : int { kCfg1024x8 = 0, kCfg1024x16 = 1, kCfg1024x32 = 2, kCfg1024x32x2 = 3 };
 
 int ConfigIndex(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount) {
   const int forced = ForcedConfigIndex();
@@ -290,6 +294,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     args.ticketCur = tickets + (pass & 1u);
     args.ticketNext = tickets + ((pass + 1) & 1u);
     args.failure = failure;
+    args.stickyFailure = sorter->stickyStatus;
     args.pass = pass;
     args.earlyValues = earlyValues ? 1u : 0u;
     args.trace = nullptr;
@@ -336,6 +341,8 @@ VkResult vrdxCreateSorter(const VrdxSorterCreateInfo* pCreateInfo, VrdxSorter* p
   hipError_t e = hipSetDevice(ordinal);
   for (int i = 0; i < vrdx::kNumTileConfigs && e == hipSuccess; ++i) e = vrdx::PrepareKernels(i);
   if (e == hipSuccess) e = vrdx::PrepareSmallSort();
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sorter->stickyStatus), sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMemset(sorter->stickyStatus, 0, sizeof(uint32_t));
   if (e == hipSuccess) {
     // Ranking mode: the single-atomic form needs a hardware property the ISA manual does not
     // promise, so it is verified here, once, on this very device; VRDX_RANK=ballot|atomic|auto.
@@ -352,6 +359,7 @@ VkResult vrdxCreateSorter(const VrdxSorterCreateInfo* pCreateInfo, VrdxSorter* p
   }
   (void)hipSetDevice(previous);
   if (e != hipSuccess) {
+    if (sorter->stickyStatus != nullptr) (void)hipFree(sorter->stickyStatus);
     delete sorter;  // reference cleanup(): nothing half-built survives (:153-158)
     return VK_ERROR_INITIALIZATION_FAILED;
   }
@@ -365,6 +373,7 @@ void vrdxDestroySorter(VrdxSorter sorter) {
 #ifdef VRDX_TRACE
   DumpTrace();
 #endif
+  if (sorter->stickyStatus != nullptr) (void)hipFree(sorter->stickyStatus);
   delete sorter;
 }
 
@@ -480,6 +489,17 @@ uint32_t vrdxHipReadStatus(VkCommandBuffer commandBuffer, VkBuffer storageBuffer
   if (hipMemcpyAsync(&word, BufferAddress(storageBuffer, storageOffset) + VRDX_OFF_FAILURE,
                      sizeof(word), hipMemcpyDeviceToHost, stream) != hipSuccess)
     return 0xFFFFFFFFu;
+  if (hipStreamSynchronize(stream) != hipSuccess) return 0xFFFFFFFFu;
+  return word;
+}
+
+uint32_t vrdxHipReadSorterStatus(VrdxSorter sorter, VkCommandBuffer commandBuffer) {
+  if (sorter == nullptr || sorter->stickyStatus == nullptr) return 0xFFFFFFFFu;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(commandBuffer);
+  uint32_t word = 0xFFFFFFFFu;
+  if (hipMemcpyAsync(&word, sorter->stickyStatus, sizeof(word), hipMemcpyDeviceToHost, stream) != hipSuccess)
+    return 0xFFFFFFFFu;
+  if (hipMemsetAsync(sorter->stickyStatus, 0, sizeof(word), stream) != hipSuccess) return 0xFFFFFFFFu;
   if (hipStreamSynchronize(stream) != hipSuccess) return 0xFFFFFFFFu;
   return word;
 }

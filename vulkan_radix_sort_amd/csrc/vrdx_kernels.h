@@ -36,7 +36,7 @@ struct TileConfig {
   int subTiles;  // 1: onesweep_kernel; 2: onesweep_pair_kernel (two sub-tiles per workgroup and status row)
   uint32_t tileKeys() const { return (uint32_t)threads * (uint32_t)keysPerThread * (uint32_t)subTiles; }
 };
-constexpr int kNumTileConfigs = 10;
+constexpr int kNumTileConfigs = 4;
 extern const TileConfig kTileConfigs[kNumTileConfigs];
 
 struct OnesweepArgs {
@@ -55,7 +55,8 @@ struct OnesweepArgs {
   uint32_t statusRows;
   uint32_t* ticketCur;
   uint32_t* ticketNext;
-  uint32_t* failure;
+  uint32_t* failure;          // word in the caller's storage: this sort's (cleared when the next sort is recorded)
+  uint32_t* stickyFailure;    // the sorter's own word: OR over every sort recorded with it (vrdxHipReadSorterStatus)
   uint32_t pass;              // 0..3: digit = (key >> 8 * pass) & 255
   uint32_t earlyValues;       // KV: fetch the values right after the ranking instead of after the look-back
   unsigned long long* trace;  // phase stamps, 8 per tile; nullptr outside tools/trace.sh builds

@@ -328,7 +328,7 @@ typedef u32x4 u32x4_a4 __attribute__((aligned(4)));  // 16-byte access, 4-byte a
 
 template <int THREADS>
 __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t tile, int tid, uint32_t* lds,
-                                             uint32_t* failure, uint32_t* traceTripsRows) {
+                                             uint32_t* failure, uint32_t* stickyFailure, uint32_t* traceTripsRows) {
   constexpr int GROUPS = THREADS / 256;
   constexpr int W = kLookBackWindow;
   int32_t* const pos = reinterpret_cast<int32_t*>(lds);
@@ -392,6 +392,7 @@ __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t ti
       if (!done && advance == 0) {
         if (++spins > kSpinLimit) {
           atomicOr(failure, 1u);  // bounded: give up (result unspecified) rather than hang the GPU
+          if (stickyFailure != nullptr) atomicOr(stickyFailure, 1u);  // the sorter's word: survives the next sort's clear
           done = true;
         } else {
           __builtin_amdgcn_s_sleep(1);
@@ -851,7 +852,7 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   // ---- decoupled look-back over the preceding tiles, then publish the inclusive prefix --------
   uint32_t lookBackTrace = 0;
   if (tile != 0 && !(kAblate & 1u))
-    exclusive = LookBack<THREADS>(a.statusCur, tile, tid, waveHist, a.failure, &lookBackTrace);
+    exclusive = LookBack<THREADS>(a.statusCur, tile, tid, waveHist, a.failure, a.stickyFailure, &lookBackTrace);
   if (tid < 256) {
     if (!lastTile)
       StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid],
@@ -1086,7 +1087,8 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
 
   // ---- one look-back for both sub-tiles ----------------------------------------------------------
   uint32_t lookBackTrace = 0;
-  if (tile != 0) exclusive = LookBack<THREADS>(a.statusCur, tile, tid, lookScratch, a.failure, &lookBackTrace);
+  if (tile != 0)
+    exclusive = LookBack<THREADS>(a.statusCur, tile, tid, lookScratch, a.failure, a.stickyFailure, &lookBackTrace);
   if (tid < 256) {
     if (!lastTile)
       StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid],
@@ -1353,8 +1355,9 @@ static void LaunchPairConfig(hipStream_t stream, uint32_t grid, bool keyValue, b
   }
 }
 
+// Every geometry here is selected by ConfigIndex (vrdx_api.cpp) for some size range; nothing else is built.
 const TileConfig kTileConfigs[kNumTileConfigs] = {
-    {512, 16, 1}, {1024, 16, 1}, {512, 32, 1}, {1024, 8, 1}, {512, 24, 1}, {512, 28, 1}, {512, 20, 1}, {1024, 32, 1}, {1024, 32, 2}, {512, 32, 2},
+    {1024, 8, 1}, {1024, 16, 1}, {1024, 32, 1}, {1024, 32, 2},
 };
 
 hipError_t PrepareKernels(int configIndex) {
@@ -1367,16 +1370,10 @@ hipError_t PrepareKernels(int configIndex) {
     if (e != hipSuccess) return e;
   }
   switch (configIndex) {
-    case 0: return PrepareConfig<512, 16>();
+    case 0: return PrepareConfig<1024, 8>();
     case 1: return PrepareConfig<1024, 16>();
-    case 2: return PrepareConfig<512, 32>();
-    case 3: return PrepareConfig<1024, 8>();
-    case 4: return PrepareConfig<512, 24>();
-    case 5: return PrepareConfig<512, 28>();
-    case 6: return PrepareConfig<512, 20>();
-    case 7: return PrepareConfig<1024, 32>();
-    case 8: return PreparePairConfig<1024, 32>();
-    case 9: return PreparePairConfig<512, 32>();
+    case 2: return PrepareConfig<1024, 32>();
+    case 3: return PreparePairConfig<1024, 32>();
     default: return hipErrorInvalidValue;
   }
 }
@@ -1461,16 +1458,10 @@ void LaunchHistogram(hipStream_t stream, uint32_t grid, const uint32_t* keys, ui
 void LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool keyValue, bool atomicRank,
                     const OnesweepArgs& args) {
   switch (configIndex) {
-    case 0: LaunchConfig<512, 16>(stream, grid, keyValue, atomicRank, args); break;
+    case 0: LaunchConfig<1024, 8>(stream, grid, keyValue, atomicRank, args); break;
     case 1: LaunchConfig<1024, 16>(stream, grid, keyValue, atomicRank, args); break;
-    case 2: LaunchConfig<512, 32>(stream, grid, keyValue, atomicRank, args); break;
-    case 3: LaunchConfig<1024, 8>(stream, grid, keyValue, atomicRank, args); break;
-    case 4: LaunchConfig<512, 24>(stream, grid, keyValue, atomicRank, args); break;
-    case 5: LaunchConfig<512, 28>(stream, grid, keyValue, atomicRank, args); break;
-    case 6: LaunchConfig<512, 20>(stream, grid, keyValue, atomicRank, args); break;
-    case 7: LaunchConfig<1024, 32>(stream, grid, keyValue, atomicRank, args); break;
-    case 8: LaunchPairConfig<1024, 32>(stream, grid, keyValue, atomicRank, args); break;
-    case 9: LaunchPairConfig<512, 32>(stream, grid, keyValue, atomicRank, args); break;
+    case 2: LaunchConfig<1024, 32>(stream, grid, keyValue, atomicRank, args); break;
+    case 3: LaunchPairConfig<1024, 32>(stream, grid, keyValue, atomicRank, args); break;
     default: break;
   }
 }
