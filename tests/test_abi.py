@@ -112,3 +112,17 @@ def test_storage_layout_invariants():
     subprocess.run(["make", "-C", native, "layout_check"], check=True, capture_output=True)
     r = subprocess.run([os.path.join(native, "layout_check")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and ", 0 failures" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_bench_py_launcher_refuses_more_gpus_than_present():
+    """`python bench.py --gpus N` without a launcher starts its own ranks in a child process -- unless
+    the node has fewer GPUs than asked for (here: none), which is an error, never a silent N = 1."""
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("enough GPUs")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 2 and "exposes" in r.stderr and not r.stdout.strip()

@@ -1,0 +1,168 @@
+"""GPU tests of the batched many-arrays variant (BASELINE.json configs[4]) and of the bench driver's
+hip / rocprim backends, on however many GPUs the box has (one on the
+driver's test box: the front ends size themselves from the device count).
+
+  * HipShardExecutor (one VrdxSorter + stream + storage per GPU) against the oracle: 8 arrays of
+    mixed sizes, keys-only and key+value, all sharing the executor's one storage buffer;
+  * BatchedSorter over a real process group with the nccl (= RCCL) backend, world_size = the number of
+    GPUs, launched through torch.distributed.run BEFORE anything in this process touches a GPU context
+    of its own (a child process);
+  * `bench/bench hip --devices G`: the same variant from one C++ host process, records exchanged with
+    ncclAllGather;
+  * `bench/bench hip` and `bench/bench rocprim` sweeps: the reference's protocol, its correctness check
+    and its CSV (bench/bench.cc:41-112,116-207; bench/cuda_benchmark.cu:37-126 analogue).
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench", "bench")
+
+
+def _bench_exe():
+    if not os.path.exists(BENCH):
+        subprocess.run(["make", "-C", os.path.dirname(BENCH)], check=True)
+    return BENCH
+
+
+def test_hip_shard_executor_sorts_mixed_arrays_through_one_storage(oracle):
+    import torch
+    from vulkan_radix_sort_amd.batched import BatchedSorter, HipShardExecutor
+    device = torch.cuda.current_device()
+    ex = HipShardExecutor(device)
+    sizes = [1 << 20, 5000, (1 << 22) + 12345, 70001, 1, 16385, 3_000_001, 262144]
+    arrays, expected = [], []
+    for i, n in enumerate(sizes):
+        k, v = oracle.generate(100 + i, n, 32 if i % 3 else 12)
+        dk = torch.from_numpy(k.view(np.int32).copy()).cuda(device)
+        dv = torch.from_numpy(v.view(np.int32).copy()).cuda(device) if i % 2 == 0 else None
+        arrays.append((dk, dv))
+        expected.append(oracle.sort(k, v if dv is not None else None))
+    bs = BatchedSorter(executor=ex)  # no process group: one rank owning every array
+    assert bs.my_indices(len(sizes)) == list(range(len(sizes)))
+    records = bs.sort_shard(arrays)
+    assert len(records) == 1 and records[0].status == 0 and records[0].items == sum(sizes)
+    for (dk, dv), (ek, ev, _) in zip(arrays, expected):
+        assert np.array_equal(dk.cpu().numpy().view(np.uint32), ek)
+        if dv is not None:
+            assert np.array_equal(dv.cpu().numpy().view(np.uint32), ev)
+    # wrong residency / element size are refused, not mis-sorted
+    with pytest.raises(TypeError):
+        ex.enqueue([(torch.zeros(8, dtype=torch.int64, device=f"cuda:{device}"), None)])
+    with pytest.raises(ValueError):
+        ex.enqueue([(torch.zeros(8, dtype=torch.int32), None)])
+    ex.close()
+
+
+_WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["VRDX_ROOT"])
+from oracle import load_oracle
+from vulkan_radix_sort_amd.batched import BatchedSorter, HipShardExecutor
+rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+torch.cuda.set_device(local)
+dist.init_process_group("nccl")
+orc = load_oracle()
+bs = BatchedSorter(executor=HipShardExecutor(local))
+assert bs.world_size == world and bs.rank == rank
+num = 8
+mine = bs.my_indices(num)
+arrays, want = [], []
+for i in mine:
+    k, v = orc.generate(i + 1, 200000 + 1237 * i, 32)
+    arrays.append((torch.from_numpy(k.view(np.int32).copy()).cuda(local), torch.from_numpy(v.view(np.int32).copy()).cuda(local)))
+    want.append(orc.sort(k, v))
+records = bs.sort_shard(arrays)
+assert [r.rank for r in records] == list(range(world)) and all(r.status == 0 for r in records)
+assert sum(r.items for r in records) == sum(200000 + 1237 * i for i in range(num))
+for (dk, dv), (ek, ev, _) in zip(arrays, want):
+    assert np.array_equal(dk.cpu().numpy().view(np.uint32), ek) and np.array_equal(dv.cpu().numpy().view(np.uint32), ev)
+if rank == 0:
+    print("BATCHED_OK world=%d" % world)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_batched_sorter_over_rccl_on_every_gpu_of_the_box(tmp_path):
+    import torch
+    gpus = torch.cuda.device_count()
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    env = dict(os.environ, VRDX_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and f"BATCHED_OK world={gpus}" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_bench_py_reports_the_ranks_it_ran_and_refuses_a_mismatch():
+    """`python bench.py --gpus G` (no launcher) starts its own G ranks; with more GPUs asked for than the
+    box has it exits non-zero instead of silently measuring fewer."""
+    import torch
+    gpus = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus + 1), "--steps", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "exposes" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1",
+                        "--log2n", "22", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == gpus and line["unit"] == "GItems/s" and line["value"] > 0
+    assert len(line["config"]["ranks"]) == gpus and all(x["status"] == 0 for x in line["config"]["ranks"])
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
+
+
+def test_bench_driver_batched_mode_in_cpp():
+    """bench hip --devices G: one host process, one sorter + stream + storage per GPU, ncclAllGather of the
+    per-GPU records; checked against the cpu backend (array 0 of every GPU) and by sortedness + checksum."""
+    import torch
+    gpus = torch.cuda.device_count()
+    r = subprocess.run([_bench_exe(), "hip", "--devices", str(gpus), "--arrays", "4", "--log2n", "21"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Correctness check passed (4 arrays)" in r.stdout and f"over {gpus} GPU(s)" in r.stdout
+    assert r.stdout.count("status 0") == gpus
+    r = subprocess.run([_bench_exe(), "hip", "--devices", str(gpus + 1)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "exposes" in r.stderr
+
+
+@pytest.mark.parametrize("backend,points,lo,hi", [("hip", 3, 18, 22), ("rocprim", 2, 18, 20)])
+def test_bench_driver_backends(tmp_path, backend, points, lo, hi):
+    """The reference's protocol end to end on the GPU: one-shot correctness check against the cpu backend,
+    then the sweep; CSV = the reference's seven columns + achieved_GBps + hbm_fraction."""
+    out = tmp_path / f"{backend}.csv"
+    r = subprocess.run([_bench_exe(), backend, "--points", str(points), "--min-log2n", str(lo), "--max-log2n", str(hi),
+                        "-o", str(out)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Correctness check passed" in r.stdout
+    lines = [l for l in out.read_text().splitlines() if not l.startswith("#")]
+    assert lines[0] == "backend,n,sort,gpu_ms,cpu_ms,gpu_gitems_s,cpu_gitems_s,achieved_GBps,hbm_fraction"
+    rows = [l.split(",") for l in lines[1:]]
+    assert len(rows) == 2 * points and [r_[2] for r_ in rows] == ["keys", "kv"] * points
+    assert all(r_[0] == backend and float(r_[3]) > 0 and 0 < float(r_[8]) < 1 for r_ in rows)
+    assert int(rows[0][1]) == 1 << lo and int(rows[-1][1]) == 1 << hi
+    if backend == "hip":
+        assert out.read_text().startswith("# version: vrdx-hip")
