@@ -126,3 +126,17 @@ def test_bench_py_launcher_refuses_more_gpus_than_present():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        timeout=300, env=env)
     assert r.returncode == 2 and "exposes" in r.stderr and not r.stdout.strip()
+
+
+def test_host_code_under_address_and_ub_sanitizers(tmp_path):
+    """ASan + UBSan build of everything that runs on the host without a GPU: vrdx_layout.h, the oracle
+    (vrdx_oracle.c, cpu_sort.cc) and the bench driver's cpu backend (GPU sanitizers do not exist on this pool)."""
+    san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g", "-O1"]
+    obj = tmp_path / "vrdx_oracle.o"
+    subprocess.run(["gcc", "-std=c99", "-c", os.path.join(ROOT, "oracle", "vrdx_oracle.c"), "-o", str(obj)] + san, check=True)
+    exe = tmp_path / "sanitized_host_check"
+    subprocess.run(["g++", "-std=c++17", os.path.join(ROOT, "tests", "native", "sanitized_host_check.cpp"),
+                    os.path.join(ROOT, "oracle", "cpu_sort.cc"), str(obj), "-o", str(exe)] + san, check=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "0 failures" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

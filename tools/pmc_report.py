@@ -3,11 +3,36 @@
 per launch for the sort kernels, calibrated on the copy kernels of the same run.
 
     python tools/pmc_report.py <fetch_counter_collection.csv> <write_counter_collection.csv> N [out.json]
+
+The output is stamped with the library it was measured on (its version string and the SHA-256 of the
+kernel / host sources): bench.py quotes `roofline.traffic` from profiles/pmc_traffic.json only while
+that stamp matches the library it is benchmarking, and reports null otherwise.
 """
 import csv
+import hashlib
 import json
+import os
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_digest():
+    h = hashlib.sha256()
+    for name in ("vrdx_kernels.hip", "vrdx_kernels.h", "vrdx_layout.h", "vrdx_api.cpp"):
+        with open(os.path.join(ROOT, "vulkan_radix_sort_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def library_version():
+    sys.path.insert(0, ROOT)
+    try:
+        import vulkan_radix_sort_amd as vrdx
+        return vrdx.version_string()
+    except Exception as e:  # the stamp is then unusable, and bench.py will say traffic = null
+        return "unknown (%s)" % e
 
 
 def per_kernel(path, counter):
@@ -36,7 +61,7 @@ def main():
     f16 = known / pick(fetch, "copy_uint4")     # 16 B/lane reads
     w4 = known / pick(write, "copy_dword")
     w16 = known / pick(write, "copy_uint4")
-    out = {"n": n, "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; counter units "
+    out = {"n": n, "library": library_version(), "kernel_source_sha256": kernel_source_digest(), "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; counter units "
                              "calibrated on copy kernels of known size in the same run (4 B/lane and 16 B/lane)",
            "bytes_per_fetch_unit": {"dword": f4, "uint4": f16}, "bytes_per_write_unit": {"dword": w4, "uint4": w16},
            "kernels": {}}
