@@ -39,5 +39,32 @@ def main(path):
               f" of the rest: mean {np.delete(lb, first).mean() if tiles > len(first) else 0:.2f}")
 
 
+def timeline(path, bin_us=2.0):
+    """Lock-step evidence: for every pass, how many tiles are in which phase in each time bin.  The
+    phases that move HBM bytes are load+rank (loads in flight) and scatter (stores issued, draining into
+    the next bins); with one workgroup per CU at most 256 tiles exist at a time."""
+    raw = np.fromfile(path, dtype=np.uint32, count=1)
+    tiles = int(raw[0])
+    data = np.fromfile(path, dtype=np.uint64, offset=4).reshape(4, tiles, 8)
+    print("\n# tiles per phase in %.0f us bins (columns: t_us ticket load+rank hist/scan regroup look-back scatter | in flight)" % bin_us)
+    for p in range(4):
+        t = data[p, :, :7].astype(np.int64)
+        rel = (t - t[:, 0].min()) / 100.0
+        end = rel[:, 6].max()
+        print(f"pass {p}:")
+        idle = 0
+        edges = np.arange(0.0, end + bin_us, bin_us)
+        for lo in edges[:-1]:
+            mid = lo + bin_us / 2
+            counts = [int(((rel[:, i] <= mid) & (mid < rel[:, i + 1])).sum()) for i in range(6)]
+            memory = counts[1] + counts[5]
+            if memory < 64:
+                idle += 1
+            print("  %6.1f  %s | %d" % (lo, " ".join("%4d" % c for c in counts), sum(counts)))
+        print(f"  bins with fewer than 64 of 256 CUs in a memory phase (load+rank or scatter): {idle} of {len(edges) - 1}")
+
+
 if __name__ == "__main__":
     main(sys.argv[1])
+    if len(sys.argv) > 2 and sys.argv[2] == "timeline":
+        timeline(sys.argv[1])
