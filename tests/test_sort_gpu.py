@@ -330,6 +330,24 @@ def test_every_size_regime_matches_oracle(torch_mod, sorter, oracle, n):
     assert np.array_equal(gk, ek) and np.array_equal(gp, ep)
 
 
+# Key+value sorts of 2^24 < N <= 3 * 2^24 elements read their tiles with non-temporal loads (a second
+# copy of the load sequence in the key+value kernels, vrdx_kernels.hip StreamingLoads): both edges of the
+# window from both sides, ragged sizes inside it, and an indirect sort whose host-side bound is above the
+# window while the device-side count is inside it (the kernel decides from the count it sorts).
+@pytest.mark.parametrize("n", [(1 << 24) + 1, (1 << 24) + 32769 + 77, 3 << 24, (3 << 24) + 1])
+def test_key_value_streaming_load_window(torch_mod, sorter, oracle, n):
+    k, _ = oracle.generate(21, n, 32)
+    iota = np.arange(n, dtype=np.uint32)
+    ek, ep, _ = oracle.sort(k, iota)
+    gk, gp = gpu_sort(torch_mod, sorter, k, iota)
+    assert np.array_equal(gk, ek) and np.array_equal(gp, ep)
+    if n == (3 << 24) + 1:
+        count = 20_000_003
+        ek, ep, _ = oracle.sort(k, iota, count=count)
+        gk, gp = gpu_sort(torch_mod, sorter, k, iota, count=count, indirect=True, max_count=n)
+        assert np.array_equal(gk, ek) and np.array_equal(gp, ep)
+
+
 @pytest.mark.parametrize("n", [70_001, 3_000_001, 9_000_001, (1 << 24) + 5])
 def test_constant_digit_passes_are_copied_correctly(torch_mod, sorter, oracle, n):
     """A pass whose digit is the same for every key is the identity permutation; the kernels detect it

@@ -20,6 +20,7 @@ for v in $VARIANTS; do
       $flags -x hip vrdx_kernels.hip vrdx_api.cpp -shared -o $d/libvrdx_hip.so) || exit 1
   for c in $CONFIGS; do
     echo "=== variant=$name ($flags) config=$c" | tee -a "$OUT"
-    LD_LIBRARY_PATH=$d VRDX_TILE_CONFIG=$c timeout 120 $ROOT/tests/native/vrdx_selftest bench $LOGS 2>&1 | tail -n +3 | tee -a "$OUT"
+    if [ "$c" = auto ]; then unset VRDX_TILE_CONFIG; else export VRDX_TILE_CONFIG=$c; fi  # auto: the size-adaptive choice
+    LD_LIBRARY_PATH=$d timeout 120 $ROOT/tests/native/vrdx_selftest bench $LOGS 2>&1 | tail -n +3 | tee -a "$OUT"
   done
 done

@@ -22,6 +22,12 @@ constexpr uint32_t kHistCopies = VRDX_HIST_COPIES;
 constexpr uint32_t kHistWorkgroupsPerCu = VRDX_HIST_WGS_PER_CU;
 constexpr uint32_t kHistCopiesLarge = 32;          // sorts of kHistManyCopiesFrom keys and more
 constexpr uint32_t kHistManyCopiesFrom = 1u << 24;
+// key+value sorts of more than kStreamingLoadsAbove and at most kStreamingLoadsUpTo elements read their
+// tiles with non-temporal loads (vrdx_kernels.hip, StreamingLoads): 16 B per element = 1x ... 3x the 256 MiB
+// Infinity Cache of an MI355X
+constexpr uint32_t kHistStreamingLoadsAbove = 1u << 25;  // histogram: keys (4 B each) of more than half that cache
+constexpr uint32_t kStreamingLoadsAbove = 1u << 24;
+constexpr uint32_t kStreamingLoadsUpTo = 3u << 24;
 constexpr uint32_t HistLdsBytes(uint32_t copies) { return 4u * 256u * copies * 4u; }  // [pass][digit][copy]
 #ifndef VRDX_HIST_UNROLL
 #define VRDX_HIST_UNROLL 4

@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "vrdx_kernels.h"
 #include "vrdx_layout.h"
 
@@ -38,6 +40,19 @@ namespace vrdx {
 #define VRDX_ABLATE 0
 #endif
 constexpr uint32_t kAblate = VRDX_ABLATE;
+
+// Cache-policy switches for measurements (tools/variants.sh, tools/nt_sweep.sh).  VRDX_STREAMING_LOADS:
+// 0 never, 1 by size (the product, see StreamingLoads below), 2 always; VRDX_HIST_NT: the same three values
+// for the histogram's key loads.  VRDX_NT_STORES: the `nt` bit on the scatter stores (off: measured, a loss).
+#ifndef VRDX_STREAMING_LOADS
+#define VRDX_STREAMING_LOADS 1
+#endif
+#ifndef VRDX_NT_STORES
+#define VRDX_NT_STORES 0
+#endif
+#ifndef VRDX_HIST_NT
+#define VRDX_HIST_NT 1
+#endif
 
 
 // Timing-only phase trace for tools/trace.sh (never defined in the product build): thread 0 of
@@ -56,6 +71,9 @@ constexpr uint32_t kAblate = VRDX_ABLATE;
 // ---------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));  // 16-byte access, 4-byte aligned
 
 // Tile status words cross CUs and XCDs inside one launch: every access is a relaxed agent-scope
 // atomic (global_load/store ... sc1).  The word carries its own flag, so no fence is needed
@@ -107,21 +125,50 @@ __device__ __forceinline__ void LdsBarrier() {
 // compiler use ONE offset register plus immediates for all the loads (SGPR base + VGPR offset +
 // imm) instead of a 64-bit address pair per load -- 60 registers that the two-sub-tile kernel
 // does not have.
-template <int KPT>
+template <int KPT, bool NT = false>
 __device__ __forceinline__ void LoadStriped(const uint32_t* base, uint32_t first, uint32_t n, bool full,
                                             uint32_t pad, uint32_t (&out)[KPT]) {
   const char* const bytes = reinterpret_cast<const char*>(base);
   const uint32_t offset = first * 4u;
+  // NT: the loads carry the non-temporal bit (StreamingLoads below).  Compile-time on purpose: given both
+  // kinds of load on the two sides of a run-time branch, the compiler merges them into plain ones.
+  auto word = [&](int i) {
+    const uint32_t* const p = reinterpret_cast<const uint32_t*>(bytes + ((uint64_t)offset + (uint64_t)(i * 256)));
+    return NT ? __builtin_nontemporal_load(p) : *p;
+  };
   if (full) {
 #pragma unroll
-    for (int i = 0; i < KPT; ++i)
-      out[i] = *reinterpret_cast<const uint32_t*>(bytes + ((uint64_t)offset + (uint64_t)(i * 256)));
+    for (int i = 0; i < KPT; ++i) out[i] = word(i);
   } else {
 #pragma unroll
-    for (int i = 0; i < KPT; ++i)
-      out[i] = first + i * 64 < n
-                   ? *reinterpret_cast<const uint32_t*>(bytes + ((uint64_t)offset + (uint64_t)(i * 256)))
-                   : pad;
+    for (int i = 0; i < KPT; ++i) out[i] = first + i * 64 < n ? word(i) : pad;
+  }
+}
+
+// Key+value sorts whose four buffers (16 bytes per element) are between one and three times the
+// 256 MiB Infinity Cache read their tiles with NON-TEMPORAL loads: the reads then do not displace the
+// lines the previous pass has just written, which is what this pass reads.  Measured on MI355X
+// (tools/nt_sweep.sh, profiles/r02_streaming_loads.txt): +3 ... +11 % for 2^24 < N <= 3 * 2^24 pairs
+// (66 instead of 59 GItems/s at 2^25), nothing below, -3 ... -4 % above; keys-only sorts gain nothing at
+// any size.  The element count is the one the kernel sorts (indirect sorts included).
+__device__ __forceinline__ bool StreamingLoads(bool keyValue, uint32_t n) {
+  if (VRDX_STREAMING_LOADS == 0) return false;
+  if (VRDX_STREAMING_LOADS == 2) return true;
+  return keyValue && n > kStreamingLoadsAbove && n <= kStreamingLoadsUpTo;
+}
+
+// LoadStriped with the kind of load chosen at run time (uniform).  The empty asm statements keep the
+// two arms distinguishable: identical loads at the head or the tail of both would be merged into one
+// plain load.
+template <int KPT>
+__device__ __forceinline__ void LoadTile(const uint32_t* base, uint32_t first, uint32_t n, bool full, uint32_t pad,
+                                         uint32_t (&out)[KPT], bool streaming) {
+  if (streaming) {
+    asm volatile("; non-temporal tile loads" ::: "memory");
+    LoadStriped<KPT, true>(base, first, n, full, pad, out);
+    asm volatile("" ::: "memory");
+  } else {
+    LoadStriped<KPT, false>(base, first, n, full, pad, out);
   }
 }
 
@@ -266,26 +313,43 @@ __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t*
   };
 
   const uint32_t nvec = n >> 2;
-  const uint4* keys4 = reinterpret_cast<const uint4*>(keys);
+  const u32x4* keys4 = reinterpret_cast<const u32x4*>(keys);
   constexpr uint32_t kUnroll = kHistUnroll;
   const uint32_t chunk = kHistThreads * kUnroll;
-  for (uint32_t base = blockIdx.x * chunk; base < nvec; base += gridDim.x * chunk) {
-    uint4 k[kUnroll];
+  // One read of the keys, 16 bytes per lane, kUnroll loads in flight.  Inputs of more than half the
+  // 256 MiB Infinity Cache are read with non-temporal loads (little of them would still be there for
+  // pass 0): 51 instead of 55 us at N = 2^26, 90 instead of 104 us at 2^27, no difference at 2^24 and
+  // 2^25 (tools/hist_variants.sh, profiles/r02_streaming_loads.txt).
+  auto sweep = [&](auto streaming) {
+    constexpr bool NT = decltype(streaming)::value;
+    for (uint32_t base = blockIdx.x * chunk; base < nvec; base += gridDim.x * chunk) {
+      u32x4 k[kUnroll];
 #pragma unroll
-    for (uint32_t u = 0; u < kUnroll; ++u) {
-      const uint32_t i = base + u * kHistThreads + tid;
-      k[u] = i < nvec ? keys4[i] : make_uint4(0, 0, 0, 0);
-    }
+      for (uint32_t u = 0; u < kUnroll; ++u) {
+        const uint32_t i = base + u * kHistThreads + tid;
+        if (i < nvec)
+          k[u] = NT ? __builtin_nontemporal_load(keys4 + i) : keys4[i];
+        else
+          k[u] = u32x4{0, 0, 0, 0};
+      }
 #pragma unroll
-    for (uint32_t u = 0; u < kUnroll; ++u) {
-      const uint32_t i = base + u * kHistThreads + tid;
-      if (i < nvec) {
-        count(k[u].x);
-        count(k[u].y);
-        count(k[u].z);
-        count(k[u].w);
+      for (uint32_t u = 0; u < kUnroll; ++u) {
+        const uint32_t i = base + u * kHistThreads + tid;
+        if (i < nvec) {
+          count(k[u][0]);
+          count(k[u][1]);
+          count(k[u][2]);
+          count(k[u][3]);
+        }
       }
     }
+  };
+  const bool streamingInput = VRDX_HIST_NT == 2 || (VRDX_HIST_NT == 1 && n > kHistStreamingLoadsAbove);
+  if (streamingInput) {
+    asm volatile("; non-temporal key loads" ::: "memory");  // keeps the two loops apart (see LoadTile)
+    sweep(std::true_type{});
+  } else {
+    sweep(std::false_type{});
   }
   if (blockIdx.x == 0 && tid < (n & 3u)) count(keys[(nvec << 2) + tid]);
   __syncthreads();
@@ -323,8 +387,15 @@ __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t*
 constexpr int kLookBackWindow = VRDX_LOOKBACK_WINDOW;
 constexpr uint32_t kSpinLimit = 1u << 18;
 constexpr int32_t kLookBackDone = INT32_MIN;
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef u32x4 u32x4_a4 __attribute__((aligned(4)));  // 16-byte access, 4-byte aligned
+
+// One 16-byte store of a sorted quad to out[index .. index + 3] (4-byte aligned).
+__device__ __forceinline__ void StoreQuad(uint32_t* out, uint32_t index, u32x4 q) {
+  u32x4_a4* const p = reinterpret_cast<u32x4_a4*>(reinterpret_cast<char*>(out) + (uint64_t)(index * 4u));
+  if (VRDX_NT_STORES)
+    __builtin_nontemporal_store(q, p);
+  else
+    *p = q;
+}
 
 template <int THREADS>
 __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t tile, int tid, uint32_t* lds,
@@ -650,7 +721,7 @@ __device__ __forceinline__ void ScatterStagedKeys(const uint32_t* sorted, const 
     }
 #pragma unroll
     for (int b = 0; b < B; ++b)
-      if (whole[b]) *reinterpret_cast<u32x4_a4*>(reinterpret_cast<char*>(out) + (uint64_t)(o[b] * 4u)) = k4[b];
+      if (whole[b]) StoreQuad(out, o[b], k4[b]);
   }
   if (boundaryQuad != ~0u) {
     const u32x4 k4 = *reinterpret_cast<const u32x4*>(&sorted[StagingSlot<STAGE>(boundaryQuad)]);
@@ -683,7 +754,7 @@ __device__ __forceinline__ void ScatterStagedValues(const uint32_t* sorted, cons
       const uint32_t p = StagingSlot<STAGE>(4u * (tid + (j0 + b) * THREADS));
       const uint32_t d0 = digits[j0 + b] & 0xFFu, d3 = digits[j0 + b] >> 8;
       if ((kAblate & 32u) || (p + 3 < valid && d0 == d3))
-        *reinterpret_cast<u32x4_a4*>(reinterpret_cast<char*>(out) + (uint64_t)(o[b] * 4u)) = v4[b];
+        StoreQuad(out, o[b], v4[b]);
     }
   }
   if (boundaryQuad != ~0u)
@@ -786,11 +857,12 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   // Ragged last tile: pad with 0xFFFFFFFF like the reference (downsweep.slang:81).  Pads sit at the
   // highest memory positions of the tile and have digit 255 in every pass, so the stable ranking
   // puts them at tile-local positions >= valid, where nothing is written.
-  LoadStriped<KPT>(keysIn, loadBase, n, valid == TILE, 0xFFFFFFFFu, key);
+  const bool streaming = KV && StreamingLoads(KV, n);
+  LoadTile<KPT>(keysIn, loadBase, n, valid == TILE, 0xFFFFFFFFu, key, streaming);
   if (plan.copy) {  // identity permutation that has to change buffers: copy the tile
     StoreStriped<KPT>(keysOut, loadBase, n, valid == TILE, key);
     if constexpr (KV) {
-      LoadStriped<KPT>(valuesIn, loadBase, n, valid == TILE, 0u, val);
+      LoadTile<KPT>(valuesIn, loadBase, n, valid == TILE, 0u, val, streaming);
       StoreStriped<KPT>(valuesOut, loadBase, n, valid == TILE, val);
     }
     return;
@@ -810,7 +882,7 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   ForgetDerivedValues<KPT>(key);
   // key+value, early form: the values start their trip now and land during the scan and the regroup
   if constexpr (KV) {
-    if (a.earlyValues) LoadStriped<KPT>(valuesIn, loadBase, n, valid == TILE, 0u, val);  // pad: downsweep.slang:85
+    if (a.earlyValues) LoadTile<KPT>(valuesIn, loadBase, n, valid == TILE, 0u, val, streaming);  // pad: downsweep.slang:85
   }
   LdsBarrier();
   VRDX_STAMP(2);
@@ -867,7 +939,7 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   // of tiles; on the final kernels the early form is as fast or faster everywhere.  Issued right
   // before the look-back the loads queue in front of its agent-scope status reads (6 -> 9 us, measured).
   if constexpr (KV) {
-    if (!a.earlyValues) LoadStriped<KPT>(valuesIn, loadBase, n, valid == TILE, 0u, val);
+    if (!a.earlyValues) LoadTile<KPT>(valuesIn, loadBase, n, valid == TILE, 0u, val, streaming);
   }
 
   // ---- scatter (ScatterStagedKeys above); key+value replays the permutation for the values ------
