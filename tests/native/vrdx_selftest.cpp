@@ -57,7 +57,17 @@ struct Harness {
       std::fprintf(stderr, "vrdxCreateSorter failed: %d\n", (int)r);
       std::exit(2);
     }
-    HIP_OK(hipStreamCreate(&stream));
+    // VRDX_SELFTEST_CU_MASK=<hex word>: the sorts run on a stream restricted to the CUs whose bit is set in
+    // that word, repeated over all CUs (55555555 = every other CU) -- a diagnostic for how much of a pass is
+    // contention between CUs (tools: DESIGN.md section 5.3), not a mode of the library.
+    if (const char* mask = std::getenv("VRDX_SELFTEST_CU_MASK")) {
+      const uint32_t word = (uint32_t)std::strtoul(mask, nullptr, 16);
+      uint32_t words[16];
+      for (auto& w : words) w = word;
+      HIP_OK(hipExtStreamCreateWithCUMask(&stream, 16, words));
+    } else {
+      HIP_OK(hipStreamCreate(&stream));
+    }
     if (vrdxHipCreateQueryPool(15, &pool) != VK_SUCCESS) std::exit(2);
   }
   void reserve(size_t keysBytes, size_t storageBytes) {
@@ -473,11 +483,15 @@ int Adversarial(Harness& h, int lg) {
   std::vector<uint32_t> iota(n), k(n);
   for (uint32_t i = 0; i < n; ++i) iota[i] = i;
   std::mt19937 g(4);
-  const char* names[] = {"uniform", "all-equal", "all-0xFFFFFFFF", "descending", "ascending", "few-distinct(4)"};
+  // the last two: every tile holds each digit of pass 0 exactly 128 times, so every run a tile writes in
+  // pass 0 is 512 bytes -- starting on a 512-byte boundary ("balanced"), or 13 keys behind one
+  // ("balanced+13": every run then begins and ends inside a 128-byte line).  Only pass 0 is comparable.
+  const char* names[] = {"uniform", "all-equal", "all-0xFFFFFFFF", "descending", "ascending", "few-distinct(4)",
+                         "balanced", "balanced+13"};
   double base[2] = {0, 0};
   int failures = 0;
   std::printf("%-18s %-5s %10s %12s %10s %s\n", "keys", "sort", "gpu_ms", "GItems/s", "slowdown", "parity");
-  for (int pattern = 0; pattern < 6; ++pattern) {
+  for (int pattern = 0; pattern < 8; ++pattern) {
     const uint32_t four[4] = {3u, 0xFFFFFFFFu, 0x00010000u, 0x7F000000u};
     for (uint32_t i = 0; i < n; ++i) {
       switch (pattern) {
@@ -486,7 +500,9 @@ int Adversarial(Harness& h, int lg) {
         case 2: k[i] = 0xFFFFFFFFu; break;
         case 3: k[i] = n - 1 - i; break;
         case 4: k[i] = i; break;
-        default: k[i] = four[g() & 3]; break;
+        case 5: k[i] = four[g() & 3]; break;
+        case 6: k[i] = (i & 0xFFu) * 0x01010101u; break;
+        default: k[i] = i < 13 ? 0u : ((i - 13) & 0xFFu) * 0x01010101u; break;
       }
     }
     std::vector<uint32_t> ek = k, ev = iota;
