@@ -294,6 +294,17 @@ def main():
                       "whole_sort_frac": KV_BYTES_PER_ITEM * n / (med_kv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
     }
 
+    # counter-measured HBM bytes of the same kernels (profiles/pmc_traffic.json, only while its stamp matches this
+    # library) over the launch duration measured above: the "measured HBM GB/s" beside the algorithmic figure
+    if pmc:
+        roofline["traffic_GBps"] = pmc["onesweep_keys_bytes_per_launch"] / (sweep_ms * 1e-3) / 1e9
+        roofline["traffic_frac"] = roofline["traffic_GBps"] / HBM_PEAK_GBPS
+        kv_bytes = pmc.get("onesweep_key_value_bytes_per_launch")
+        if kv_bytes:
+            roofline["key_value"]["traffic"] = kv_bytes
+            roofline["key_value"]["traffic_GBps"] = kv_bytes / (sweep_kv_ms * 1e-3) / 1e9
+            roofline["key_value"]["traffic_frac"] = roofline["key_value"]["traffic_GBps"] / HBM_PEAK_GBPS
+
     result = {
         "metric": "GItems/s at N=2^25 (keys & key+value); achieved HBM GB/s vs peak",
         "value": value_keys, "unit": "GItems/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,

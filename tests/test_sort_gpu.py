@@ -248,6 +248,8 @@ def test_timestamp_contract(torch_mod, sorter, oracle):
     sp = sum(ts[3 + 3 * p] - ts[2 + 3 * p] for p in range(4))
     dn = sum(ts[4 + 3 * p] - ts[3 + 3 * p] for p in range(4))
     assert up > 0 and dn > 0 and up + sp + dn <= ts[14]
+    # the look-back is fused into the pass ("spine" = 0) and slots written back to back share one event
+    assert sp == 0 and ts[14] == ts[13] and all(ts[2 + 3 * p] == ts[1 + 3 * p] for p in range(1, 4))
     # n == 0 still records all 15 slots
     gpu_sort(torch_mod, sorter, k[:0], v[:0], query_pool=pool)
     assert len(pool.results_ns()) == 15

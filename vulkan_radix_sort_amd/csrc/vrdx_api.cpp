@@ -37,6 +37,9 @@ struct VrdxHipQueryPool {
   uint32_t count = 0;
   hipEvent_t* events = nullptr;
   uint8_t* recorded = nullptr;
+  // source[slot]: the slot whose event holds this slot's time.  Slots the sort writes back to back, with
+  // no device work between them, share ONE event record (an event record costs the stream ~3 us).
+  uint32_t* source = nullptr;
 };
 
 namespace {
@@ -169,7 +172,16 @@ void DebugCheck(const char* what) {
 
 void Stamp(VrdxHipQueryPool* pool, uint32_t slot, hipStream_t stream) {
   if (pool == nullptr || slot >= pool->count) return;
-  if (hipEventRecord(pool->events[slot], stream) == hipSuccess) pool->recorded[slot] = 1;
+  if (hipEventRecord(pool->events[slot], stream) == hipSuccess) {
+    pool->recorded[slot] = 1;
+    pool->source[slot] = slot;
+  }
+}
+// The same point of the stream as slot `same` (stamped just before, nothing enqueued since): no second event.
+void StampSame(VrdxHipQueryPool* pool, uint32_t slot, uint32_t same) {
+  if (pool == nullptr || slot >= pool->count || same >= pool->count || !pool->recorded[same]) return;
+  pool->recorded[slot] = 1;
+  pool->source[slot] = pool->source[same];
 }
 
 // reference: gpuSort, src/vk_radix_sort.h.in:344-507
@@ -214,7 +226,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
 
   if (elementCount == 0) {
     // reference: zero partitions -> every dispatch is empty (:353,448,465,487)
-    for (uint32_t s = 1; s < 15; ++s) Stamp(pool, query + s, stream);
+    for (uint32_t s = 1; s < 15; ++s) StampSame(pool, query + s, query + 0);
     return;
   }
 
@@ -223,7 +235,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   // general path below costs six launches = 30-45 us however small N is).  Forcing a tile geometry
   // (VRDX_TILE_CONFIG) also forces the general path, which is how the tests reach it at small sizes.
   if (elementCount <= vrdx::kSmallSortMaxElements && ForcedConfigIndex() < 0 && SmallSortEnabled()) {
-    for (uint32_t s = 1; s < 14; ++s) Stamp(pool, query + s, stream);
+    for (uint32_t s = 1; s < 14; ++s) StampSame(pool, query + s, query + 0);
     vrdx::LaunchSmallSort(stream, sorter->atomicRank, keys, values, elementCount, countPtr,
                           reinterpret_cast<uint32_t*>(storage + layout.failureOffset));
     DebugCheck("small_sort_kernel");
@@ -274,8 +286,13 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   static const int forcedEarly = TuningKnob("VRDX_KV_EARLY_VALUES");  // 0 | 1: tuning/testing
   if (forcedEarly >= 0) earlyValues = forcedEarly != 0;
   for (uint32_t pass = 0; pass < VRDX_PASSES; ++pass) {
-    Stamp(pool, query + 2 + 3 * pass + 0, stream);  // "upsweep" of this pass
-    Stamp(pool, query + 2 + 3 * pass + 1, stream);  // "spine" (fused into the onesweep look-back)
+    // "upsweep" of this pass: the fused histogram kernel for pass 0, nothing for the others -- the same
+    // point of the stream as the previous pass's "downsweep" stamp
+    if (pass == 0)
+      Stamp(pool, query + 2, stream);
+    else
+      StampSame(pool, query + 2 + 3 * pass + 0, query + 2 + 3 * (pass - 1) + 2);
+    StampSame(pool, query + 2 + 3 * pass + 1, query + 2 + 3 * pass + 0);  // "spine" (fused into the look-back)
 
     vrdx::OnesweepArgs args;
     // which pair of arrays the pass reads is settled on the device (vrdx_kernels.h); the reference
@@ -306,7 +323,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
 
     Stamp(pool, query + 2 + 3 * pass + 2, stream);  // "downsweep"
   }
-  Stamp(pool, query + 14, stream);
+  StampSame(pool, query + 14, query + 13);  // end of the sort = end of the last pass
 }
 
 }  // namespace
@@ -435,18 +452,22 @@ VkResult vrdxHipCreateQueryPool(uint32_t queryCount, VkQueryPool* pQueryPool) {
   if (pool == nullptr) return VK_ERROR_OUT_OF_HOST_MEMORY;
   pool->events = new (std::nothrow) hipEvent_t[queryCount];
   pool->recorded = new (std::nothrow) uint8_t[queryCount];
-  if (pool->events == nullptr || pool->recorded == nullptr) {
+  pool->source = new (std::nothrow) uint32_t[queryCount];
+  if (pool->events == nullptr || pool->recorded == nullptr || pool->source == nullptr) {
     delete[] pool->events;
     delete[] pool->recorded;
+    delete[] pool->source;
     delete pool;
     return VK_ERROR_OUT_OF_HOST_MEMORY;
   }
   std::memset(pool->recorded, 0, queryCount);
+  for (uint32_t i = 0; i < queryCount; ++i) pool->source[i] = i;
   for (uint32_t i = 0; i < queryCount; ++i) {
     if (hipEventCreate(&pool->events[i]) != hipSuccess) {
       for (uint32_t j = 0; j < i; ++j) (void)hipEventDestroy(pool->events[j]);
       delete[] pool->events;
       delete[] pool->recorded;
+      delete[] pool->source;
       delete pool;
       return VK_ERROR_INITIALIZATION_FAILED;
     }
@@ -462,6 +483,7 @@ void vrdxHipDestroyQueryPool(VkQueryPool queryPool) {
   for (uint32_t i = 0; i < pool->count; ++i) (void)hipEventDestroy(pool->events[i]);
   delete[] pool->events;
   delete[] pool->recorded;
+  delete[] pool->source;
   delete pool;
 }
 
@@ -473,8 +495,8 @@ VkResult vrdxHipGetQueryPoolResults(VkQueryPool queryPool, uint32_t firstQuery, 
   for (uint32_t i = 0; i < queryCount; ++i) {
     if (!pool->recorded[firstQuery + i]) return VK_NOT_READY;
     float ms = 0.0f;
-    const hipError_t e =
-        hipEventElapsedTime(&ms, pool->events[firstQuery], pool->events[firstQuery + i]);
+    const hipError_t e = hipEventElapsedTime(&ms, pool->events[pool->source[firstQuery]],
+                                             pool->events[pool->source[firstQuery + i]]);
     if (e == hipErrorNotReady) return VK_NOT_READY;
     if (e != hipSuccess) return VK_ERROR_DEVICE_LOST;
     pData[i] = ms <= 0.0f ? 0ull : (uint64_t)((double)ms * 1.0e6 + 0.5);
