@@ -35,7 +35,8 @@ namespace vrdx {
 // Timing-only ablation switches for tools/ablate.sh (results are WRONG when any bit is set; the
 // product build always has VRDX_ABLATE == 0):  1 no look-back   2 no match ranking
 // 4 linear instead of scattered stores   8 tile = blockIdx (no ticket)   16 no wave counters
-// 32 every quad takes the 16-byte store path
+// 32 every quad takes the 16-byte store path   64 one-tile kernel: tile = blockIdx and the keys loaded
+// before the ticket / pass plan are known (right for inputs with no trivial pass)
 #ifndef VRDX_ABLATE
 #define VRDX_ABLATE 0
 #endif
@@ -813,8 +814,15 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   VRDX_STAMP(0);
 
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
+  uint32_t key[KPT];
+  if (kAblate & 64u) {  // timing only: tile = blockIdx and the keys of the usual source requested at once
+    const uint32_t start = blockIdx.x * TILE;
+    if (start < n)
+      LoadStriped<KPT, false>((a.pass & 1u) ? a.keysScratch : a.keysCaller, start + wave * (KPT * 64) + lane, n,
+                              n - start >= TILE, 0xFFFFFFFFu, key);
+  }
   const PassCounts<THREADS> passCounts = LoadPassCounts<THREADS>(a.histogramTable, tid);
-  if (tid == 0) misc[0] = (kAblate & 8u) ? blockIdx.x : atomicAdd(a.ticketCur, 1u);
+  if (tid == 0) misc[0] = (kAblate & (8u | 64u)) ? blockIdx.x : atomicAdd(a.ticketCur, 1u);
   PublishPassVotes<THREADS>(passCounts, n, tid, planFlags);
   for (int i = tid; i < WAVES * 256; i += THREADS) waveHist[i] = 0;
   LdsBarrier();
@@ -851,14 +859,13 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
 
   // ---- load: wave-striped, so that (slot, lane) order == memory order inside a wave ----------
   // (the values are fetched once the keys have been staged)
-  uint32_t key[KPT];
   uint32_t val[KV ? KPT : 1];
   const uint32_t loadBase = tileStart + wave * (KPT * 64) + lane;
   // Ragged last tile: pad with 0xFFFFFFFF like the reference (downsweep.slang:81).  Pads sit at the
   // highest memory positions of the tile and have digit 255 in every pass, so the stable ranking
   // puts them at tile-local positions >= valid, where nothing is written.
   const bool streaming = KV && StreamingLoads(KV, n);
-  LoadTile<KPT>(keysIn, loadBase, n, valid == TILE, 0xFFFFFFFFu, key, streaming);
+  if (!(kAblate & 64u)) LoadTile<KPT>(keysIn, loadBase, n, valid == TILE, 0xFFFFFFFFu, key, streaming);
   if (plan.copy) {  // identity permutation that has to change buffers: copy the tile
     StoreStriped<KPT>(keysOut, loadBase, n, valid == TILE, key);
     if constexpr (KV) {
