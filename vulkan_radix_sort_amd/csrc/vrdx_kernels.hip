@@ -45,6 +45,16 @@ constexpr uint32_t kAblate = VRDX_ABLATE;
 // Cache-policy switches for measurements (tools/variants.sh, tools/nt_sweep.sh).  VRDX_STREAMING_LOADS:
 // 0 never, 1 by size (the product, see StreamingLoads below), 2 always; VRDX_HIST_NT: the same three values
 // for the histogram's key loads.  VRDX_NT_STORES: the `nt` bit on the scatter stores (off: measured, a loss).
+// Timing diagnostic (tools/variants.sh; results stay correct): every other workgroup of the first 256
+// waits VRDX_DEPHASE_US microseconds before it draws its ticket, so that half of the CUs run half a tile
+// behind the others.  VRDX_DEPHASE_SHIFT picks the bit of blockIdx that decides (0: alternate XCDs,
+// 3: alternate CUs inside every XCD).  Off (0) in the product.
+#ifndef VRDX_DEPHASE_US
+#define VRDX_DEPHASE_US 0
+#endif
+#ifndef VRDX_DEPHASE_SHIFT
+#define VRDX_DEPHASE_SHIFT 3
+#endif
 #ifndef VRDX_STREAMING_LOADS
 #define VRDX_STREAMING_LOADS 1
 #endif
@@ -119,6 +129,13 @@ __device__ __forceinline__ void LdsBarrier() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__device__ __forceinline__ void Dephase() {
+  if (VRDX_DEPHASE_US > 0 && ((blockIdx.x >> VRDX_DEPHASE_SHIFT) & 1u) && blockIdx.x < 256u) {
+    const uint64_t t0 = wall_clock64();  // 100 MHz
+    while (wall_clock64() - t0 < (uint64_t)VRDX_DEPHASE_US * 100u) __builtin_amdgcn_s_sleep(16);
+  }
 }
 
 // Wave-striped load of KPT words per lane: out[i] = base[first + 64 * i] (pad where the index is
@@ -812,6 +829,7 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   uint64_t stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   VRDX_STAMP(0);
+  Dephase();
 
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   uint32_t key[KPT];
@@ -1032,6 +1050,7 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
   uint64_t stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   VRDX_STAMP(0);
+  Dephase();
 
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   const PassCounts<THREADS> passCounts = LoadPassCounts<THREADS>(a.histogramTable, tid);
