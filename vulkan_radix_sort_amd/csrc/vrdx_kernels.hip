@@ -37,6 +37,8 @@ namespace vrdx {
 // 4 linear instead of scattered stores   8 tile = blockIdx (no ticket)   16 no wave counters
 // 32 every quad takes the 16-byte store path   64 one-tile kernel: tile = blockIdx and the keys loaded
 // before the ticket / pass plan are known (right for inputs with no trivial pass)
+// 128 the quads that straddle a run boundary are not written at all
+// 256 linear stores like 4, but the per-quad offset is still looked up (and discarded)
 #ifndef VRDX_ABLATE
 #define VRDX_ABLATE 0
 #endif
@@ -696,7 +698,7 @@ __device__ __forceinline__ void StoreBoundaryQuad(const uint32_t* sorted, const 
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const uint32_t d = (packedDigits >> (8 * c)) & 0xFFu;
-    if (quad + c < valid) StoreWord(out, ((kAblate & 4u) ? linearBase : offset[d]) + quad + c, q[c]);
+    if (quad + c < valid) StoreWord(out, ((kAblate & (4u | 256u)) ? linearBase : offset[d]) + quad + c, q[c]);
   }
 }
 
@@ -733,7 +735,13 @@ __device__ __forceinline__ void ScatterStagedKeys(const uint32_t* sorted, const 
       const uint32_t p = StagingSlot<STAGE>(4u * (tid + (j0 + b) * THREADS));  // involution: the sorted position
       const uint32_t d0 = (k4[b][0] >> shift) & 0xFFu, d3 = (k4[b][3] >> shift) & 0xFFu;
       whole[b] = (kAblate & 32u) || (p + 3 < valid && d0 == d3);
-      o[b] = (kAblate & 4u) ? linearBase + p : offset[d0] + p;
+      if (kAblate & 256u) {  // linear stores that still wait for their offset lookup
+        uint32_t looked = offset[d0];
+        asm volatile("v_and_b32 %0, 0, %0" : "+v"(looked));
+        o[b] = linearBase + p + looked;
+      } else {
+        o[b] = (kAblate & 4u) ? linearBase + p : offset[d0] + p;
+      }
       asm volatile("" : "+v"(o[b]));  // fetched here, for every quad: not sunk into the conditional store
       if (KEEP_DIGITS) digits[j0 + b] = d0 | (d3 << 8);
     }
@@ -741,7 +749,7 @@ __device__ __forceinline__ void ScatterStagedKeys(const uint32_t* sorted, const 
     for (int b = 0; b < B; ++b)
       if (whole[b]) StoreQuad(out, o[b], k4[b]);
   }
-  if (boundaryQuad != ~0u) {
+  if (boundaryQuad != ~0u && !(kAblate & 128u)) {
     const u32x4 k4 = *reinterpret_cast<const u32x4*>(&sorted[StagingSlot<STAGE>(boundaryQuad)]);
     boundaryDigits = ((k4[0] >> shift) & 0xFFu) | (((k4[1] >> shift) & 0xFFu) << 8) |
                      (((k4[2] >> shift) & 0xFFu) << 16) | (((k4[3] >> shift) & 0xFFu) << 24);
@@ -775,7 +783,7 @@ __device__ __forceinline__ void ScatterStagedValues(const uint32_t* sorted, cons
         StoreQuad(out, o[b], v4[b]);
     }
   }
-  if (boundaryQuad != ~0u)
+  if (boundaryQuad != ~0u && !(kAblate & 128u))
     StoreBoundaryQuad<STAGE>(sorted, offset, out, boundaryQuad, valid, boundaryDigits, linearBase);
 }
 
@@ -1054,7 +1062,7 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
 
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   const PassCounts<THREADS> passCounts = LoadPassCounts<THREADS>(a.histogramTable, tid);
-  if (tid == 0) misc[0] = atomicAdd(a.ticketCur, 1u);
+  if (tid == 0) misc[0] = (kAblate & 8u) ? blockIdx.x : atomicAdd(a.ticketCur, 1u);
   PublishPassVotes<THREADS>(passCounts, n, tid, misc + 1);
   for (int i = tid; i < WAVES * 256; i += THREADS) waveHist[i] = 0;
   LdsBarrier();
@@ -1185,7 +1193,7 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
 
   // ---- one look-back for both sub-tiles ----------------------------------------------------------
   uint32_t lookBackTrace = 0;
-  if (tile != 0)
+  if (tile != 0 && !(kAblate & 1u))
     exclusive = LookBack<THREADS>(a.statusCur, tile, tid, lookScratch, a.failure, a.stickyFailure, &lookBackTrace);
   if (tid < 256) {
     if (!lastTile)
@@ -1206,16 +1214,16 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
     uint32_t val[KPT];
     LoadStriped<KPT>(valuesIn, loadBaseA, n, validA == SUB, 0u, val);  // pad: downsweep.slang:85
     ScatterStagedKeys<THREADS, KPT, true>(sorted, offsetA, keysOut, validA, shift, tid, boundaryQuadA, digits,
-                                          boundaryDigits);
+                                          boundaryDigits, tileStart);
     LdsBarrier();
 #pragma unroll
     for (int i = 0; i < KPT; ++i) sorted[(packedPosA[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
     LdsBarrier();
     ScatterStagedValues<THREADS, KPT>(sorted, offsetA, valuesOut, validA, tid, boundaryQuadA, digits,
-                                      boundaryDigits);
+                                      boundaryDigits, tileStart);
   } else {
     ScatterStagedKeys<THREADS, KPT, false>(sorted, offsetA, keysOut, validA, shift, tid, boundaryQuadA, digits,
-                                           boundaryDigits);
+                                           boundaryDigits, tileStart);
   }
   LdsBarrier();  // the staging buffer is free again
 
@@ -1227,16 +1235,16 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
     uint32_t val[KPT];
     LoadStriped<KPT>(valuesIn, loadBaseB, n, validB == SUB, 0u, val);
     ScatterStagedKeys<THREADS, KPT, true>(sorted, offsetB, keysOut, validB, shift, tid, boundaryQuadB, digits,
-                                          boundaryDigits);
+                                          boundaryDigits, tileStart + SUB);
     LdsBarrier();
 #pragma unroll
     for (int i = 0; i < KPT; ++i) sorted[(packedPosB[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
     LdsBarrier();
     ScatterStagedValues<THREADS, KPT>(sorted, offsetB, valuesOut, validB, tid, boundaryQuadB, digits,
-                                      boundaryDigits);
+                                      boundaryDigits, tileStart + SUB);
   } else {
     ScatterStagedKeys<THREADS, KPT, false>(sorted, offsetB, keysOut, validB, shift, tid, boundaryQuadB, digits,
-                                           boundaryDigits);
+                                           boundaryDigits, tileStart + SUB);
   }
 #ifdef VRDX_TRACE
   VRDX_STAMP(6);
