@@ -1357,7 +1357,17 @@ __global__ __launch_bounds__(THREADS) void small_sort_kernel(uint32_t* keys, uin
 // ---------------------------------------------------------------------------------------------
 // Every wave ranks pseudo-random digit vectors of several entropies (constant, 2, 4, 16, 256
 // distinct values, sparse collisions) both ways and counts disagreements.  16 waves per
-// workgroup hammer the LDS at the same time.
+// workgroup hammer the LDS at the same time, in the shapes the sort kernels use: 8 slots per lane
+// unpacked (1024x8 tiles), then 32 slots per lane unpacked and packed (1024x32 tiles, keys-only and
+// key+value / two-sub-tile form), 32 atomics in flight per lane.
+__device__ __forceinline__ uint32_t OrderCheckKey(uint32_t tid, uint32_t wave, uint32_t slot) {
+  uint32_t x = (blockIdx.x * 1024u + tid) * 0x9E3779B9u + slot * 0x85EBCA6Bu;
+  x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+  const uint32_t mode = (blockIdx.x + wave + slot) % 6u;
+  const uint32_t mask = mode == 0 ? 0u : mode == 1 ? 1u : mode == 2 ? 3u : mode == 3 ? 15u : mode == 4 ? 0x21u : 255u;
+  return x & mask;
+}
+
 __global__ __launch_bounds__(1024) void lds_order_check_kernel(uint32_t* mismatches) {
   __shared__ uint32_t counters[2 * 16 * 256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1369,17 +1379,39 @@ __global__ __launch_bounds__(1024) void lds_order_check_kernel(uint32_t* mismatc
   for (uint32_t round = 0; round < 8; ++round) {
     uint32_t key[8], ra[8], rb[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      uint32_t x = (blockIdx.x * 1024u + tid) * 0x9E3779B9u + (round * 8 + i) * 0x85EBCA6Bu;
-      x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
-      const uint32_t mode = (blockIdx.x + wave + round * 8 + i) % 6u;
-      const uint32_t mask = mode == 0 ? 0u : mode == 1 ? 1u : mode == 2 ? 3u : mode == 3 ? 15u : mode == 4 ? 0x21u : 255u;
-      key[i] = x & mask;
-    }
+    for (int i = 0; i < 8; ++i) key[i] = OrderCheckKey(tid, wave, round * 8 + i);
     RankAtomic<8, false>(key, 0, histA, lane, ra);
     RankBallot<8>(key, 0, histB, lane, rb);
 #pragma unroll
     for (int i = 0; i < 8; ++i) bad += ra[i] != rb[i];
+  }
+  // the counters keep counting (both sets alike), so the ranks below stay under 2^16: 64 lanes x (64 + 64) slots.
+  // The reference ranks are packed two to a register before the atomic ones are taken (register budget).
+#pragma unroll 1
+  for (uint32_t form = 0; form < 2; ++form) {
+    uint32_t key[32], want[16];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) key[i] = OrderCheckKey(tid, wave, 64 + 32 * form + i);
+    {
+      uint32_t rb[32];
+      RankBallot<32>(key, 0, histB, lane, rb);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        want[i] = rb[2 * i] | (rb[2 * i + 1] << 16);
+        asm volatile("" : "+v"(want[i]));
+      }
+    }
+    if (form == 0) {
+      uint32_t ra[32];
+      RankAtomic<32, false>(key, 0, histA, lane, ra);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) bad += (ra[2 * i] | (ra[2 * i + 1] << 16)) != want[i];
+    } else {
+      uint32_t rp[16];
+      RankAtomic<32, true>(key, 0, histA, lane, rp);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) bad += rp[i] != want[i];
+    }
   }
   if (bad != 0) atomicAdd(mismatches, bad);
 }
