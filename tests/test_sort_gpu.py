@@ -286,8 +286,9 @@ def test_capturable_into_a_hip_graph(torch_mod, sorter, oracle):
     # VkCommandBuffer == stream-ordered enqueue: recording inside a stream capture must work.
     # tests/native/vrdx_selftest checks this with the bare HIP graph API (hipStreamBeginCapture ->
     # vrdxCmdSort* -> hipGraphLaunch) on a cold process.  Through torch.cuda.CUDAGraph the replay was
-    # observed to be a silent no-op when the FIRST launch of the sort kernels in the process
-    # happened inside the capture, so one eager sort runs first (as any real caller has done).
+    # once observed to be a silent no-op when the FIRST launch of the sort kernels in the process
+    # happened inside the capture, so one eager sort runs first here; the cold case (capture as the very
+    # first use of a new sorter in a new process) is test_graph_capture_in_a_fresh_process below.
     torch = torch_mod
     n = 200000
     k, v = oracle.generate(31, n, 32)
@@ -310,6 +311,18 @@ def test_capturable_into_a_hip_graph(torch_mod, sorter, oracle):
         torch.cuda.synchronize()
         assert np.array_equal(_to_u32(dk), ek) and np.array_equal(_to_u32(dv), ev)
         assert sorter.read_status(torch.cuda.current_stream().cuda_stream, storage.data_ptr(), 0) == 0
+
+
+def test_graph_capture_in_a_fresh_process(torch_mod):
+    """vrdxCreateSorter loads every kernel it may launch (it sets their LDS limits), so a sort may be
+    captured into a graph as the first thing a process does with the sorter: general path and
+    single-workgroup path, checked against the oracle by tests/cold_capture_check.py."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "cold_capture_check.py")], cwd=ROOT,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count(": OK") == 2 and "NOT SORTED" not in out.stdout, out.stdout + out.stderr
 
 
 # one size inside every regime of the size-adaptive tile selection (ConfigIndex in vrdx_api.cpp; f =
