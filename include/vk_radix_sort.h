@@ -190,7 +190,9 @@ uint32_t vrdxHipReadStatus(VkCommandBuffer commandBuffer, VkBuffer storageBuffer
 /* The same diagnosis for EVERY sort recorded with this sorter since the previous call (or since
  * vrdxCreateSorter), whatever storage they used: the OR of their failure bits, kept in a device
  * word the sorter owns; reading it clears it.  This is what a caller that runs many sorts through
- * one storage buffer checks once at the end.  Synchronises the given stream (which must belong to
+ * one storage buffer checks once at the end.  Bit 31 is the host side of it: set when the runtime
+ * refused one of the sort's enqueues (fill, copy, kernel launch) -- the vrdxCmdSort* entry points return
+ * void, so this is where such an error surfaces.  Synchronises the given stream (which must belong to
  * the sorter's device and be ordered after the sorts in question). */
 uint32_t vrdxHipReadSorterStatus(VrdxSorter sorter, VkCommandBuffer commandBuffer);
 

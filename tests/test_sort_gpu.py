@@ -325,6 +325,17 @@ def test_graph_capture_in_a_fresh_process(torch_mod):
     assert out.stdout.count(": OK") == 2 and "NOT SORTED" not in out.stdout, out.stdout + out.stderr
 
 
+def test_refused_enqueue_is_latched_in_the_sorter_status(torch_mod):
+    """vrdxCmdSort* return void; an enqueue the runtime refuses shows up as bit 31 of
+    vrdxHipReadSorterStatus, once (tests/enqueue_error_check.py, in a process of its own because the
+    test hook is read once per process)."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "enqueue_error_check.py")], cwd=ROOT,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
 # one size inside every regime of the size-adaptive tile selection (ConfigIndex in vrdx_api.cpp; f =
 # N / (256 CUs * 32768)): 1024x8 | 1024x16 | 1024x32 | two-sub-tile 1024x32x2 | 1024x16 between
 # rounds | ... -- all ragged (odd) sizes

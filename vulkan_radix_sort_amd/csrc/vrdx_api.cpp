@@ -11,6 +11,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -30,6 +31,10 @@ struct VrdxSorter_T {
   // vrdxHipReadSorterStatus clears it, so a caller that reuses ONE storage buffer for many sorts (each
   // of which clears the storage's own failure word) still learns about a failure in any of them.
   uint32_t* stickyStatus = nullptr;
+  // Host side of the same diagnosis: set when an enqueue of a sort (fill, copy or kernel launch) was
+  // refused by the runtime -- the entry points return void, so this is the only place it can go.
+  // Reported as bit 31 by vrdxHipReadSorterStatus, which clears it.
+  mutable std::atomic<uint32_t> enqueueFailed{0};
   // reference: VrdxSorter_T::minStorageBufferOffsetAlignment (src/vk_radix_sort.h.in:134)
   uint32_t minStorageBufferOffsetAlignment = VRDX_STORAGE_ALIGN;
 };
@@ -165,10 +170,16 @@ bool DebugEnabled() {
   static const bool enabled = std::getenv("VRDX_DEBUG") != nullptr;
   return enabled;
 }
-void DebugCheck(const char* what) {
-  if (!DebugEnabled()) return;
-  const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) std::fprintf(stderr, "vrdx-hip: %s -> %s\n", what, hipGetErrorString(e));
+// After every enqueue of a sort: a refused launch / fill / copy is latched in the sorter (and printed
+// under VRDX_DEBUG).  hipPeekAtLastError: the caller's own view of the last error is left as it is.
+void EnqueueCheck(const VrdxSorter_T* sorter, const char* what, hipError_t returned = hipSuccess) {
+  hipError_t e = returned != hipSuccess ? returned : hipPeekAtLastError();
+  // test hook (tests/enqueue_error_check.py): every check reports a refusal, the work itself is enqueued as usual
+  static const bool inject = std::getenv("VRDX_TEST_INJECT_ENQUEUE_ERROR") != nullptr;
+  if (inject) e = hipErrorUnknown;
+  if (e == hipSuccess) return;
+  sorter->enqueueFailed.store(1u, std::memory_order_relaxed);
+  if (DebugEnabled()) std::fprintf(stderr, "vrdx-hip: %s -> %s\n", what, hipGetErrorString(e));
 }
 
 void Stamp(VrdxHipQueryPool* pool, uint32_t slot, hipStream_t stream) {
@@ -239,7 +250,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     for (uint32_t s = 1; s < 14; ++s) StampSame(pool, query + s, query + 0);
     vrdx::LaunchSmallSort(stream, sorter->atomicRank, keys, values, elementCount, countPtr,
                           reinterpret_cast<uint32_t*>(storage + layout.failureOffset));
-    DebugCheck("small_sort_kernel");
+    EnqueueCheck(sorter, "small_sort_kernel");
     Stamp(pool, query + 14, stream);
     return;
   }
@@ -248,11 +259,11 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   // region 0 in one fill.  Indirect: also copy the device-side count to where the reference keeps
   // it (:368-379); the kernels themselves read it straight from the caller's buffer.  (Direct: the
   // count travels as a kernel argument, the slot stays 0 -- storage contents are scratch.)
-  (void)hipMemsetAsync(storage, 0, layout.clearBytes, stream);
-  DebugCheck("hipMemsetAsync(state)");
+  EnqueueCheck(sorter, "hipMemsetAsync(state)", hipMemsetAsync(storage, 0, layout.clearBytes, stream));
   if (countPtr != nullptr)
-    (void)hipMemcpyAsync(storage + layout.countOffset, countPtr, sizeof(uint32_t),
-                         hipMemcpyDeviceToDevice, stream);
+    EnqueueCheck(sorter, "hipMemcpyAsync(count)",
+                 hipMemcpyAsync(storage + layout.countOffset, countPtr, sizeof(uint32_t), hipMemcpyDeviceToDevice,
+                                stream));
   Stamp(pool, query + 1, stream);
 
   uint32_t* const globalHistogram = reinterpret_cast<uint32_t*>(storage + layout.histogramOffset);
@@ -279,7 +290,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     static const int forcedGrid = TuningKnob("VRDX_HIST_GRID");  // tools/hist_grid.sh
     if (forcedGrid > 0) grid = (uint32_t)forcedGrid;
     vrdx::LaunchHistogram(stream, grid, keys, elementCount, countPtr, globalHistogram, tickets);
-    DebugCheck("histogram_kernel");
+    EnqueueCheck(sorter, "histogram_kernel");
   }
 
   const uint32_t tiles = vrdx::RoundUp(elementCount, tileKeys);
@@ -324,7 +335,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     args.trace = TraceBuffer(pass, tiles);
 #endif
     vrdx::LaunchOnesweep(stream, configIndex, tiles, keyValue, sorter->atomicRank, args);
-    DebugCheck("onesweep_kernel");
+    EnqueueCheck(sorter, "onesweep_kernel");
 
     Stamp(pool, query + 2 + 3 * pass + 2, stream);  // "downsweep"
   }
@@ -528,6 +539,7 @@ uint32_t vrdxHipReadSorterStatus(VrdxSorter sorter, VkCommandBuffer commandBuffe
     return 0xFFFFFFFFu;
   if (hipMemsetAsync(sorter->stickyStatus, 0, sizeof(word), stream) != hipSuccess) return 0xFFFFFFFFu;
   if (hipStreamSynchronize(stream) != hipSuccess) return 0xFFFFFFFFu;
+  if (sorter->enqueueFailed.exchange(0u, std::memory_order_relaxed) != 0) word |= 0x80000000u;
   return word;
 }
 
