@@ -90,6 +90,54 @@ __global__ __launch_bounds__(THREADS) void read_kernel(const uint32_t* __restric
   }
 }
 
+// The sort kernels' own access pattern: a workgroup reads one tile of THREADS * KPT keys, every wave KPT
+// rows of 64 consecutive dwords (4 bytes per lane per load, KPT loads in flight per lane); VEC = 4: the
+// same bytes as 16-byte loads (KPT / 4 of them per lane).
+template <int THREADS, int KPT, int VEC>
+__global__ __launch_bounds__(THREADS) void tile_read_kernel(const uint32_t* __restrict__ keys, uint32_t n,
+                                                            uint32_t* __restrict__ out) {
+  const uint32_t tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t base = tile * (THREADS * KPT) + wave * (KPT * 64);
+  uint32_t acc = 0;
+  if (VEC == 1) {
+    uint32_t k[KPT];
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) k[i] = keys[base + i * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) acc ^= k[i];
+  } else {
+    const uint4* keys4 = reinterpret_cast<const uint4*>(keys + base);
+    uint4 k[KPT / 4];
+#pragma unroll
+    for (int i = 0; i < KPT / 4; ++i) k[i] = keys4[i * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < KPT / 4; ++i) acc ^= k[i].x ^ k[i].y ^ k[i].z ^ k[i].w;
+  }
+  if (acc == 0x12345678u) atomicAdd(out, 1u);
+}
+
+template <int THREADS, int KPT, int VEC>
+static void RunTile(const uint32_t* keys, uint32_t n, uint32_t* out) {
+  auto fn = tile_read_kernel<THREADS, KPT, VEC>;
+  const int grid = (int)(n / (THREADS * KPT));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(fn, dim3(grid), dim3(THREADS), 0, 0, keys, n, out);
+  CHECK(hipDeviceSynchronize());
+  const int reps = 20;
+  CHECK(hipEventRecord(e0));
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(fn, dim3(grid), dim3(THREADS), 0, 0, keys, n, out);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  const double us = ms * 1000.0 / reps;
+  printf("tile read: threads=%4d keys/thread=%2d bytes/lane/load=%2d tiles=%5d  %7.2f us  %5.2f TB/s\n", THREADS, KPT,
+         4 * VEC, grid, us, 4.0 * n / us * 1e-6);
+  fflush(stdout);
+}
+
 template <int THREADS, int U, int MODE, int COPIES, bool NT>
 static void Run(const uint32_t* keys, uint32_t n, uint32_t* out, int grid, int cus) {
   const size_t lds = MODE >= 1 ? (size_t)4 * 256 * COPIES * 4 : 0;
@@ -139,6 +187,15 @@ int main(int argc, char** argv) {
   for (int g : {1, 2}) Run<1024, 4, 0, 8, false>(keys, n, out, cus * g, cus);
   for (int g : {1, 2}) Run<1024, 8, 0, 8, false>(keys, n, out, cus * g, cus);
   for (int g : {1, 2}) Run<1024, 2, 0, 8, false>(keys, n, out, cus * g, cus);
+  puts("-- the sort kernels' tile read: one tile per workgroup, wave-striped");
+  RunTile<1024, 32, 1>(keys, n, out);
+  RunTile<1024, 32, 4>(keys, n, out);
+  RunTile<1024, 16, 1>(keys, n, out);
+  RunTile<1024, 16, 4>(keys, n, out);
+  RunTile<1024, 8, 1>(keys, n, out);
+  RunTile<512, 32, 1>(keys, n, out);
+  RunTile<256, 32, 1>(keys, n, out);
+  RunTile<256, 32, 4>(keys, n, out);
   puts("-- pure read, non-temporal loads");
   for (int g : {1, 2}) Run<1024, 4, 0, 8, true>(keys, n, out, cus * g, cus);
   for (int g : {4, 8}) Run<256, 4, 0, 8, true>(keys, n, out, cus * g, cus);
