@@ -313,6 +313,39 @@ def test_capturable_into_a_hip_graph(torch_mod, sorter, oracle):
         assert sorter.read_status(torch.cuda.current_stream().cuda_stream, storage.data_ptr(), 0) == 0
 
 
+def _random_cases(count, seed):
+    """(n, bits, key+value, indirect, count) drawn from a fixed stream: sizes log-uniform over 1 .. 3 M (every
+    path: single workgroup, 1024x8 / x16 / x32 tiles), keys of 0 .. 32 significant bits (0, 8, 16, 24: passes
+    with a constant digit are skipped or copied), shifted into a random byte position."""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(count):
+        n = int(2 ** rng.uniform(0, np.log2(3_000_000)))
+        bits = int(rng.choice([0, 1, 3, 8, 12, 16, 24, 32]))
+        shift = int(rng.integers(0, 33 - bits)) if bits < 32 else 0
+        kv = bool(rng.integers(0, 2))
+        indirect = bool(rng.integers(0, 2))
+        cnt = int(rng.integers(0, n + 1)) if indirect else None
+        cases.append((n, bits, shift, kv, indirect, cnt))
+    return cases
+
+
+@pytest.mark.parametrize("batch", range(4))
+def test_randomized_sizes_entropies_and_modes(torch_mod, sorter, oracle, batch):
+    """48 cases per run (4 batches of 12) from a fixed random stream: any size, any key width at any bit
+    position, keys-only or key+value (values = iota), direct or indirect with any device-side count --
+    each bit-exact against the oracle, the tail beyond the count untouched."""
+    for n, bits, shift, kv, indirect, cnt in _random_cases(12, 1000 + batch):
+        k, _ = oracle.generate(7 * batch + n % 13, n, bits)
+        k = (k << np.uint32(shift)).astype(np.uint32) if shift else k
+        v = np.arange(n, dtype=np.uint32) if kv else None
+        gk, gv = gpu_sort(torch_mod, sorter, k, v, count=cnt, indirect=indirect, max_count=n if indirect else None)
+        ek, ev, _ = oracle.sort(k, v, count=cnt)
+        what = "n=%d bits=%d shift=%d kv=%s indirect=%s count=%s" % (n, bits, shift, kv, indirect, cnt)
+        assert np.array_equal(gk, ek), what
+        assert not kv or np.array_equal(gv, ev), what
+
+
 def test_graph_capture_in_a_fresh_process(torch_mod):
     """vrdxCreateSorter loads every kernel it may launch (it sets their LDS limits), so a sort may be
     captured into a graph as the first thing a process does with the sorter: general path and
