@@ -1,12 +1,15 @@
 """The host half of vrdxHipReadSorterStatus: an enqueue the runtime refuses is latched in the sorter and
 reported once as bit 31.  A real refusal cannot be provoked safely (a destroyed stream crashes the runtime,
-a bad pointer would fault the GPU), so the library's test hook VRDX_TEST_INJECT_ENQUEUE_ERROR makes every
+a bad pointer would fault the GPU), so the TEST BUILD of the library (make -C vulkan_radix_sort_amd/csrc testing,
+-DVRDX_TESTING; the product has no such hook) has VRDX_TEST_INJECT_ENQUEUE_ERROR, which makes every
 check report one while the work is enqueued as usual.  Run in a process of its own by tests/test_sort_gpu.py."""
 import os
 import sys
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["VRDX_TEST_INJECT_ENQUEUE_ERROR"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["VRDX_LIBRARY"] = os.path.join(ROOT, "build", "testing", "libvrdx_hip.so")  # the -DVRDX_TESTING build
+sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 import vulkan_radix_sort_amd as vrdx

@@ -62,6 +62,41 @@ def test_hip_shard_executor_sorts_mixed_arrays_through_one_storage(oracle):
     ex.close()
 
 
+def test_one_gpus_share_of_the_batched_config_at_full_size(oracle, golden):
+    """BASELINE.json configs[4] at G = 1: the eight independent N = 2^25 key+value arrays (seeds 1..8, the reference's
+    generator) that the 8-GPU run shards one per GPU, sorted here by ONE GPU's executor through its one storage
+    buffer.  Seeds 1 and 2 against the committed checksums of the reference's CPU sort, the rest by
+    size-independent properties on the GPU (sorted, same multiset of keys and of values); sticky status 0."""
+    import torch
+    from vulkan_radix_sort_amd.batched import BatchedSorter, HipShardExecutor
+    device = torch.cuda.current_device()
+    n = 1 << 25
+    ex = HipShardExecutor(device)
+    bs = BatchedSorter(executor=ex)
+    arrays, sums = [], []
+    for seed in range(1, 9):
+        k, v = oracle.generate(seed, n, 32)
+        dk = torch.from_numpy(k.view(np.int32)).cuda(device)
+        dv = torch.from_numpy(v.view(np.int32)).cuda(device)
+        arrays.append((dk, dv))
+        sums.append((int(k.astype(np.uint64).sum()), int(v.astype(np.uint64).sum())))
+        del k, v
+    records = bs.sort_shard(arrays)
+    assert len(records) == 1 and records[0].status == 0 and records[0].items == 8 * n
+    for seed, (dk, dv) in enumerate(arrays, start=1):
+        uk = dk.to(torch.int64) & 0xFFFFFFFF
+        assert bool((uk[1:] >= uk[:-1]).all()), seed
+        assert int(uk.sum().item()) == sums[seed - 1][0], seed
+        assert int((dv.to(torch.int64) & 0xFFFFFFFF).sum().item()) == sums[seed - 1][1], seed
+        del uk
+        rows = [h for h in golden["hashes"] if h["n"] == n and h["seed"] == seed and h["bits"] == 32]
+        if rows:
+            assert f"{oracle.hash(dk.cpu().numpy().view(np.uint32)):016x}" == rows[0]["sorted_keys_hash"], seed
+            assert f"{oracle.hash(dv.cpu().numpy().view(np.uint32)):016x}" == rows[0]["sorted_values_hash"], seed
+    assert sum(1 for h in golden["hashes"] if h["n"] == n and h["bits"] == 32 and h["seed"] in (1, 2)) == 2
+    ex.close()
+
+
 _WORKER = r'''
 import os, sys
 import numpy as np

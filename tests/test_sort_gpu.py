@@ -208,6 +208,66 @@ def test_buffer_offsets_and_shared_buffer(torch_mod, sorter, oracle):
     assert not storage[:pad].any()  # nothing before storageOffset
 
 
+def test_storage_requirements_through_the_c_abi_match_the_golden_table(sorter, golden):
+    """the sizes the exported calculators return (vrdxGetSorter[KeyValue]StorageRequirements through
+    ctypes, on the GPU box's sorter) equal the table computed from the reference's formulas
+    (src/vk_radix_sort.h.in:279-308), row by row; usage = STORAGE_BUFFER | TRANSFER_DST."""
+    assert golden["usage"] == 0x22
+    for row in golden["storage_align16"]:
+        k = sorter.storage_requirements(row["n"])
+        kv = sorter.key_value_storage_requirements(row["n"])
+        assert (k.size, k.usage) == (row["keys"], 0x22), row
+        assert (kv.size, kv.usage) == (row["key_value"], 0x22), row
+
+
+@pytest.mark.parametrize("n", [70_001, 3_000_001])
+def test_direct_modes_with_buffer_offsets_and_a_query_offset(torch_mod, sorter, oracle, n):
+    """vrdxCmdSort / vrdxCmdSortKeyValue with non-zero keysOffset, valuesOffset and storageOffset (keys and values
+    in ONE buffer, bench/vulkan_benchmark.cc:346-358) and the timestamps at [query, query + 15) of a larger pool
+    (src/vk_radix_sort.h.in:39-50): query = 7 of 22 slots; the slots before stay unwritten, and
+    vrdxHipGetQueryPoolResults(firstQuery = 7) reports the sort's 15 slots relative to its first."""
+    import vulkan_radix_sort_amd as vrdx
+    torch = torch_mod
+    k, v = oracle.generate(21, n, 32)
+    ek, ev, _ = oracle.sort(k, v)
+    inout = (n * 4 + 15) // 16 * 16
+    lead = 4096  # keysOffset
+    host = np.full(lead + 2 * inout + 64, 0xEE, dtype=np.uint8)
+    host[lead:lead + n * 4] = k.view(np.uint8)
+    host[lead + inout:lead + inout + n * 4] = v.view(np.uint8)
+    stream = torch.cuda.current_stream().cuda_stream
+    pad = 8192  # storageOffset
+    for kv in (False, True):
+        buf = torch.from_numpy(host.copy()).cuda()
+        req = sorter.key_value_storage_requirements(n) if kv else sorter.storage_requirements(n)
+        storage = torch.zeros(req.size + pad, dtype=torch.uint8, device="cuda")
+        pool = vrdx.QueryPool(22)
+        if kv:
+            sorter.cmd_sort_key_value(stream, n, buf.data_ptr(), lead, buf.data_ptr(), lead + inout,
+                                      storage.data_ptr(), pad, pool, 7)
+        else:
+            sorter.cmd_sort(stream, n, buf.data_ptr(), lead, storage.data_ptr(), pad, pool, 7)
+        torch.cuda.synchronize()
+        out = buf.cpu().numpy()
+        assert np.array_equal(out[lead:lead + n * 4].view(np.uint32), ek)
+        if kv:
+            assert np.array_equal(out[lead + inout:lead + inout + n * 4].view(np.uint32), ev)
+        else:
+            assert np.array_equal(out[lead + inout:lead + inout + n * 4].view(np.uint32), v)   # values untouched
+        assert bool((out[:lead] == 0xEE).all()) and bool((out[lead + n * 4:lead + inout] == 0xEE).all())
+        assert bool((out[lead + inout + n * 4:] == 0xEE).all())
+        assert not storage[:pad].any()                                   # nothing before storageOffset
+        assert sorter.read_status(stream, storage.data_ptr(), pad) == 0
+        ts = pool.results_ns(7, 15)
+        assert len(ts) == 15 and ts[0] == 0 and all(b >= a for a, b in zip(ts, ts[1:])) and ts[14] > 0
+        assert ts[4] - ts[3] > 0                                         # pass 0's "downsweep"
+        with pytest.raises(vrdx.VrdxError):                              # slots 0..6 were never written: VK_NOT_READY
+            pool.results_ns(0, 7)
+        with pytest.raises(vrdx.VrdxError):                              # beyond the pool
+            pool.results_ns(8, 15)
+        pool.destroy()
+
+
 def test_clean_storage_reuse_and_repeat(torch_mod, sorter, oracle):
     torch = torch_mod
     n = 300000
@@ -369,6 +429,17 @@ def test_refused_enqueue_is_latched_in_the_sorter_status(torch_mod):
     assert out.returncode == 0, out.stdout + out.stderr
 
 
+def test_device_failure_is_sticky_in_the_sorter_status(torch_mod):
+    """A look-back that gives up (forced in the -DVRDX_TESTING build by a spin limit of 0) sets the storage's
+    failure word and the sorter's sticky word; the next sort on that storage clears only the former
+    (tests/sticky_status_check.py, in a process of its own)."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sticky_status_check.py")], cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
 # one size inside every regime of the size-adaptive tile selection (ConfigIndex in vrdx_api.cpp; f =
 # N / (256 CUs * 32768)): 1024x8 | 1024x16 | 1024x32 | two-sub-tile 1024x32x2 | 1024x16 between
 # rounds | ... -- all ragged (odd) sizes
@@ -491,6 +562,11 @@ def test_full_size_adversarial(torch_mod, sorter, oracle):
         ties = gk[1:] == gk[:-1]
         assert bool(np.all(gp[1:][ties] > gp[:-1][ties])), name
         assert int(gp.astype(np.uint64).sum()) == n * (n - 1) // 2, name
+        if name in ("descending", "few-distinct"):        # ~6 s of CPU each: the full bit-exact check
+            ek, ep, _ = oracle.sort(k, iota)
+            assert np.array_equal(gk, ek) and np.array_equal(gp, ep), name
+            gk, _ = gpu_sort(torch, sorter, k)
+            assert np.array_equal(gk, ek), name
 
 
 def test_large_ragged_2pow28_properties(torch_mod, sorter):

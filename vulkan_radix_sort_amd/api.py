@@ -74,6 +74,11 @@ class VrdxSorterStorageRequirements(ctypes.Structure):
 
 
 def library_path() -> str:
+    """The in-tree libvrdx_hip.so.  VRDX_LIBRARY names another BUILD of the same library instead (the -DVRDX_TESTING
+    build of two tests, a tuning variant of tools/); it is never a fallback: a missing file is an error either way."""
+    override = os.environ.get("VRDX_LIBRARY")
+    if override:
+        return os.path.abspath(override)
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvrdx_hip.so")
 
 

@@ -94,7 +94,8 @@ enum : int { kCfg1024x8 = 0, kCfg1024x16 = 1, kCfg1024x32 = 2, kCfg1024x32x2 = 3
 
 int ConfigIndex(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount) {
   const int forced = ForcedConfigIndex();
-  if (forced >= 0) return forced;
+  // (the two-sub-tile kernel is keys-only: a key+value sort under a forced 1024x32x2 takes 1024x32)
+  if (forced >= 0) return forced == kCfg1024x32x2 && (keyValue || !sorter->atomicRank) ? kCfg1024x32 : forced;
   const double f = (double)elementCount / ((double)sorter->computeUnits * 32768.0);
   if (keyValue) {
     if (f <= 0.26) return kCfg1024x8;
@@ -170,16 +171,19 @@ bool DebugEnabled() {
   static const bool enabled = std::getenv("VRDX_DEBUG") != nullptr;
   return enabled;
 }
-// After every enqueue of a sort: a refused launch / fill / copy is latched in the sorter (and printed
-// under VRDX_DEBUG).  hipPeekAtLastError: the caller's own view of the last error is left as it is.
-void EnqueueCheck(const VrdxSorter_T* sorter, const char* what, hipError_t returned = hipSuccess) {
-  hipError_t e = returned != hipSuccess ? returned : hipPeekAtLastError();
-  // test hook (tests/enqueue_error_check.py): every check reports a refusal, the work itself is enqueued as usual
+// After every enqueue of a sort: a launch / fill / copy the runtime REFUSED is latched in the sorter (and
+// printed under VRDX_DEBUG).  Only the value returned by that very call is looked at -- never the calling
+// thread's last-error state, which is sticky on ROCm and may hold an unrelated, older failure of the caller's.
+void EnqueueCheck(const VrdxSorter_T* sorter, const char* what, hipError_t returned) {
+#ifdef VRDX_TESTING
+  // test build only (tests/enqueue_error_check.py builds it): every check reports a refusal, the work itself is
+  // enqueued as usual
   static const bool inject = std::getenv("VRDX_TEST_INJECT_ENQUEUE_ERROR") != nullptr;
-  if (inject) e = hipErrorUnknown;
-  if (e == hipSuccess) return;
+  if (inject) returned = hipErrorUnknown;
+#endif
+  if (returned == hipSuccess) return;
   sorter->enqueueFailed.store(1u, std::memory_order_relaxed);
-  if (DebugEnabled()) std::fprintf(stderr, "vrdx-hip: %s -> %s\n", what, hipGetErrorString(e));
+  if (DebugEnabled()) std::fprintf(stderr, "vrdx-hip: %s -> %s\n", what, hipGetErrorString(returned));
 }
 
 void Stamp(VrdxHipQueryPool* pool, uint32_t slot, hipStream_t stream) {
@@ -248,9 +252,9 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   // (VRDX_TILE_CONFIG) also forces the general path, which is how the tests reach it at small sizes.
   if (elementCount <= vrdx::kSmallSortMaxElements && ForcedConfigIndex() < 0 && SmallSortEnabled()) {
     for (uint32_t s = 1; s < 14; ++s) StampSame(pool, query + s, query + 0);
-    vrdx::LaunchSmallSort(stream, sorter->atomicRank, keys, values, elementCount, countPtr,
-                          reinterpret_cast<uint32_t*>(storage + layout.failureOffset));
-    EnqueueCheck(sorter, "small_sort_kernel");
+    EnqueueCheck(sorter, "small_sort_kernel",
+                 vrdx::LaunchSmallSort(stream, sorter->atomicRank, keys, values, elementCount, countPtr,
+                                       reinterpret_cast<uint32_t*>(storage + layout.failureOffset)));
     Stamp(pool, query + 14, stream);
     return;
   }
@@ -289,8 +293,8 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     if (grid == 0) grid = 1;
     static const int forcedGrid = TuningKnob("VRDX_HIST_GRID");  // tools/hist_grid.sh
     if (forcedGrid > 0) grid = (uint32_t)forcedGrid;
-    vrdx::LaunchHistogram(stream, grid, keys, elementCount, countPtr, globalHistogram, tickets);
-    EnqueueCheck(sorter, "histogram_kernel");
+    EnqueueCheck(sorter, "histogram_kernel",
+                 vrdx::LaunchHistogram(stream, grid, keys, elementCount, countPtr, globalHistogram, tickets));
   }
 
   const uint32_t tiles = vrdx::RoundUp(elementCount, tileKeys);
@@ -329,13 +333,20 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     args.failure = failure;
     args.stickyFailure = sorter->stickyStatus;
     args.pass = pass;
+    args.spinLimit = vrdx::kSpinLimit;
+#ifdef VRDX_TESTING
+    // test build only: VRDX_TEST_SPIN_LIMIT=0 makes the first look-back trip that has to wait give up, which is how
+    // tests/sticky_status_check.py sees the device-side failure path (failure word + the sorter's sticky word)
+    static const int testSpinLimit = TuningKnob("VRDX_TEST_SPIN_LIMIT");
+    if (testSpinLimit >= 0) args.spinLimit = (uint32_t)testSpinLimit;
+#endif
     args.earlyValues = earlyValues ? 1u : 0u;
     args.trace = nullptr;
 #ifdef VRDX_TRACE
     args.trace = TraceBuffer(pass, tiles);
 #endif
-    vrdx::LaunchOnesweep(stream, configIndex, tiles, keyValue, sorter->atomicRank, args);
-    EnqueueCheck(sorter, "onesweep_kernel");
+    EnqueueCheck(sorter, "onesweep_kernel",
+                 vrdx::LaunchOnesweep(stream, configIndex, tiles, keyValue, sorter->atomicRank, args));
 
     Stamp(pool, query + 2 + 3 * pass + 2, stream);  // "downsweep"
   }
@@ -537,8 +548,9 @@ uint32_t vrdxHipReadSorterStatus(VrdxSorter sorter, VkCommandBuffer commandBuffe
   uint32_t word = 0xFFFFFFFFu;
   if (hipMemcpyAsync(&word, sorter->stickyStatus, sizeof(word), hipMemcpyDeviceToHost, stream) != hipSuccess)
     return 0xFFFFFFFFu;
-  if (hipMemsetAsync(sorter->stickyStatus, 0, sizeof(word), stream) != hipSuccess) return 0xFFFFFFFFu;
-  if (hipStreamSynchronize(stream) != hipSuccess) return 0xFFFFFFFFu;
+  const hipError_t cleared = hipMemsetAsync(sorter->stickyStatus, 0, sizeof(word), stream);
+  // the copy above targets `word` on this stack frame: never return while it may still be in flight
+  if (hipStreamSynchronize(stream) != hipSuccess || cleared != hipSuccess) return 0xFFFFFFFFu;
   if (sorter->enqueueFailed.exchange(0u, std::memory_order_relaxed) != 0) word |= 0x80000000u;
   return word;
 }

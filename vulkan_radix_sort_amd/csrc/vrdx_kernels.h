@@ -20,7 +20,10 @@ namespace vrdx {
 constexpr uint32_t kHistThreads = VRDX_HIST_THREADS;
 constexpr uint32_t kHistCopies = VRDX_HIST_COPIES;
 constexpr uint32_t kHistWorkgroupsPerCu = VRDX_HIST_WGS_PER_CU;
-constexpr uint32_t kHistCopiesLarge = 32;          // sorts of kHistManyCopiesFrom keys and more
+#ifndef VRDX_HIST_COPIES_LARGE
+#define VRDX_HIST_COPIES_LARGE 32
+#endif
+constexpr uint32_t kHistCopiesLarge = VRDX_HIST_COPIES_LARGE;  // sorts of kHistManyCopiesFrom keys and more
 constexpr uint32_t kHistManyCopiesFrom = 1u << 24;
 // key+value sorts of more than kStreamingLoadsAbove and at most kStreamingLoadsUpTo elements read their
 // tiles with non-temporal loads (vrdx_kernels.hip, StreamingLoads): 16 B per element = 1x ... 3x the 256 MiB
@@ -45,6 +48,10 @@ struct TileConfig {
 constexpr int kNumTileConfigs = 4;
 extern const TileConfig kTileConfigs[kNumTileConfigs];
 
+// Every spin is bounded: a look-back that makes no progress for this many trips sets the failure word and goes on
+// (result unspecified) instead of hanging the GPU.
+constexpr uint32_t kSpinLimit = 1u << 18;
+
 struct OnesweepArgs {
   // The pass reads one pair of arrays and writes the other; which is which is decided ON THE DEVICE
   // (trivial passes are skipped, see PassPlan in vrdx_kernels.hip): with four ranking passes it is
@@ -64,6 +71,7 @@ struct OnesweepArgs {
   uint32_t* failure;          // word in the caller's storage: this sort's (cleared when the next sort is recorded)
   uint32_t* stickyFailure;    // the sorter's own word: OR over every sort recorded with it (vrdxHipReadSorterStatus)
   uint32_t pass;              // 0..3: digit = (key >> 8 * pass) & 255
+  uint32_t spinLimit;         // look-back trips without progress before the tile gives up (kSpinLimit)
   uint32_t earlyValues;       // KV: fetch the values right after the ranking instead of after the look-back
   unsigned long long* trace;  // phase stamps, 8 per tile; nullptr outside tools/trace.sh builds
 };
@@ -72,19 +80,19 @@ struct OnesweepArgs {
 hipError_t PrepareKernels(int configIndex);
 
 // Also zeroes the two tile tickets (they live outside the cleared prefix of the storage).
-void LaunchHistogram(hipStream_t stream, uint32_t grid, const uint32_t* keys, uint32_t maxCount,
-                     const uint32_t* countPtr, uint32_t* globalHistogram, uint32_t* tickets);
+hipError_t LaunchHistogram(hipStream_t stream, uint32_t grid, const uint32_t* keys, uint32_t maxCount,
+                           const uint32_t* countPtr, uint32_t* globalHistogram, uint32_t* tickets);
 
 // atomicRank selects the one-LDS-atomic-per-key ranking; only legal when LdsOrderCheck() said so.
-void LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool keyValue, bool atomicRank,
-                    const OnesweepArgs& args);
+hipError_t LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool keyValue, bool atomicRank,
+                          const OnesweepArgs& args);
 
 // Small sorts (maxCount <= kSmallSortMaxElements): the whole sort in one workgroup and one launch,
 // in place in keys / values (values == nullptr: keys-only); of the storage only *failure is written (0).
 constexpr uint32_t kSmallSortMaxElements = 16384;
 hipError_t PrepareSmallSort();
-void LaunchSmallSort(hipStream_t stream, bool atomicRank, uint32_t* keys, uint32_t* values, uint32_t maxCount,
-                     const uint32_t* countPtr, uint32_t* failure);
+hipError_t LaunchSmallSort(hipStream_t stream, bool atomicRank, uint32_t* keys, uint32_t* values, uint32_t maxCount,
+                           const uint32_t* countPtr, uint32_t* failure);
 
 // Runs the device self-check of the LDS same-address atomic ordering on the current device
 // (synchronous, ~1 ms).  *laneOrdered = true when returning atomics are served in lane order.

@@ -32,31 +32,9 @@
 
 namespace vrdx {
 
-// Timing-only ablation switches for tools/ablate.sh (results are WRONG when any bit is set; the
-// product build always has VRDX_ABLATE == 0):  1 no look-back   2 no match ranking
-// 4 linear instead of scattered stores   8 tile = blockIdx (no ticket)   16 no wave counters
-// 32 every quad takes the 16-byte store path   64 one-tile kernel: tile = blockIdx and the keys loaded
-// before the ticket / pass plan are known (right for inputs with no trivial pass)
-// 128 the quads that straddle a run boundary are not written at all
-// 256 linear stores like 4, but the per-quad offset is still looked up (and discarded)
-#ifndef VRDX_ABLATE
-#define VRDX_ABLATE 0
-#endif
-constexpr uint32_t kAblate = VRDX_ABLATE;
-
 // Cache-policy switches for measurements (tools/variants.sh, tools/nt_sweep.sh).  VRDX_STREAMING_LOADS:
 // 0 never, 1 by size (the product, see StreamingLoads below), 2 always; VRDX_HIST_NT: the same three values
 // for the histogram's key loads.  VRDX_NT_STORES: the `nt` bit on the scatter stores (off: measured, a loss).
-// Timing diagnostic (tools/variants.sh; results stay correct): every other workgroup of the first 256
-// waits VRDX_DEPHASE_US microseconds before it draws its ticket, so that half of the CUs run half a tile
-// behind the others.  VRDX_DEPHASE_SHIFT picks the bit of blockIdx that decides (0: alternate XCDs,
-// 3: alternate CUs inside every XCD).  Off (0) in the product.
-#ifndef VRDX_DEPHASE_US
-#define VRDX_DEPHASE_US 0
-#endif
-#ifndef VRDX_DEPHASE_SHIFT
-#define VRDX_DEPHASE_SHIFT 3
-#endif
 #ifndef VRDX_STREAMING_LOADS
 #define VRDX_STREAMING_LOADS 1
 #endif
@@ -65,6 +43,9 @@ constexpr uint32_t kAblate = VRDX_ABLATE;
 #endif
 #ifndef VRDX_HIST_NT
 #define VRDX_HIST_NT 1
+#endif
+#ifndef VRDX_HIST_EARLY_LOADS
+#define VRDX_HIST_EARLY_LOADS 1
 #endif
 
 
@@ -131,13 +112,6 @@ __device__ __forceinline__ void LdsBarrier() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
-__device__ __forceinline__ void Dephase() {
-  if (VRDX_DEPHASE_US > 0 && ((blockIdx.x >> VRDX_DEPHASE_SHIFT) & 1u) && blockIdx.x < 256u) {
-    const uint64_t t0 = wall_clock64();  // 100 MHz
-    while (wall_clock64() - t0 < (uint64_t)VRDX_DEPHASE_US * 100u) __builtin_amdgcn_s_sleep(16);
-  }
 }
 
 // Wave-striped load of KPT words per lane: out[i] = base[first + 64 * i] (pad where the index is
@@ -252,7 +226,6 @@ __device__ __forceinline__ PassPlan ReadPassPlan(const uint32_t* flags, uint32_t
 #pragma unroll
   for (uint32_t q = 0; q < VRDX_PASSES; ++q)
     if ((flags[4 * q] | flags[4 * q + 1] | flags[4 * q + 2] | flags[4 * q + 3]) != 0) trivial |= 1u << q;
-  if (kAblate != 0) trivial = 0;
   const uint32_t ranked = VRDX_PASSES - (uint32_t)__popc(trivial);
   // odd number of ranking passes: the first trivial pass copies, so that the result ends at the caller
   const uint32_t copier = (ranked & 1u) ? (uint32_t)(__ffs(trivial) - 1) : VRDX_PASSES;
@@ -302,11 +275,31 @@ __device__ __forceinline__ uint32_t BlockExclusiveScan256(uint32_t v, uint32_t* 
 // LDS counters are replicated COPIES times (copy = lane % COPIES, copies of one bin in consecutive
 // banks) so that all-equal / few-distinct keys do not serialise on one LDS address the way the
 // reference's 512-way atomicAdd on localHistogram[radix] does (upsweep.slang:34).  With 32 copies
-// (128 KiB, one workgroup per CU) two lanes of a wave can only meet in a bank if they are 32 apart,
-// so every ds_add takes at most two passes whatever the keys are: constant, sorted and few-distinct
-// inputs sort 6-8 % faster at N = 2^25 than with 8 copies (uniform keys: no difference, the kernel
-// is not LDS-bound there).  Clearing and reducing 128 KiB costs ~3 us, so sorts below 2^24 keys use
-// 8 copies (32 KiB).
+// every lane of a 32-lane access group has a bank of its own, so a ds_add_u32 takes its 4 LDS cycles
+// whatever the keys are (measured, tools/probes/lds_op_rate.hip: 4.0 cycles with 32 copies, 4.25 with 16,
+// 6.3 with 8): 4 atomics per key are 14 us per CU at N = 2^25 against 21 us for the read itself, so the
+// kernel is bound by the read -- PROVIDED the loads of the next group are in flight while a group is
+// counted.  Round 2's kernel loaded a group, waited, counted, and only then loaded again: a memory
+// latency plus a counting phase per 64 KiB and CU, 35 us.  Here every wave keeps TWO groups of four
+// 16-byte loads per lane in flight (128 KiB per CU) and counts the older one; the loads are
+// unconditional (index clamped, the count masked) because a branch around a load makes the compiler
+// wait for vmcnt(0) at the join.
+//
+// The grid-stride order matters as well: at any time the workgroups read ONE contiguous window of the input.  With
+// one contiguous range per workgroup the same loop takes 37 instead of 30 us at N = 2^25
+// (profiles/r03_chain_free_pass0.txt, "flatc").
+constexpr uint32_t kHistGroupVecs = kHistThreads * 4;      // 16-byte vectors per group (4 per lane)
+
+template <bool NT>
+__device__ __forceinline__ void HistFetch(const u32x4* keys4, uint32_t group, uint32_t tid, uint32_t nvec,
+                                          u32x4 (&k)[4]) {
+#pragma unroll
+  for (uint32_t u = 0; u < 4; ++u) {
+    uint32_t i = group * kHistGroupVecs + u * kHistThreads + tid;
+    i = i < nvec ? i : (nvec != 0 ? nvec - 1 : 0u);  // out-of-range lanes re-read the last vector (never counted)
+    k[u] = NT ? __builtin_nontemporal_load(keys4 + i) : keys4[i];
+  }
+}
 
 template <uint32_t COPIES>
 __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t* __restrict__ keys,
@@ -320,9 +313,6 @@ __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t*
   if (blockIdx.x == 0 && tid < 2) tickets[tid] = 0;  // outside the cleared prefix of the storage (vrdx_layout.h)
   const uint32_t n = ElementCount(maxCount, countPtr);
 
-  for (uint32_t i = tid; i < VRDX_PASSES * VRDX_RADIX * COPIES; i += kHistThreads) bins[i] = 0;
-  __syncthreads();
-
   const uint32_t copy = tid & (COPIES - 1);
   auto count = [&](uint32_t key) {
 #pragma unroll
@@ -331,41 +321,47 @@ __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t*
       atomicAdd(&bins[(p * VRDX_RADIX + d) * COPIES + copy], 1u);
     }
   };
-
-  const uint32_t nvec = n >> 2;
-  const u32x4* keys4 = reinterpret_cast<const u32x4*>(keys);
-  constexpr uint32_t kUnroll = kHistUnroll;
-  const uint32_t chunk = kHistThreads * kUnroll;
-  // One read of the keys, 16 bytes per lane, kUnroll loads in flight.  Inputs of more than half the
-  // 256 MiB Infinity Cache are read with non-temporal loads (little of them would still be there for
-  // pass 0): 51 instead of 55 us at N = 2^26, 90 instead of 104 us at 2^27, no difference at 2^24 and
-  // 2^25 (tools/hist_variants.sh, profiles/r02_streaming_loads.txt).
-  auto sweep = [&](auto streaming) {
-    constexpr bool NT = decltype(streaming)::value;
-    for (uint32_t base = blockIdx.x * chunk; base < nvec; base += gridDim.x * chunk) {
-      u32x4 k[kUnroll];
+  auto tally = [&](uint32_t group, const u32x4 (&k)[4], uint32_t nvec) {
 #pragma unroll
-      for (uint32_t u = 0; u < kUnroll; ++u) {
-        const uint32_t i = base + u * kHistThreads + tid;
-        if (i < nvec)
-          k[u] = NT ? __builtin_nontemporal_load(keys4 + i) : keys4[i];
-        else
-          k[u] = u32x4{0, 0, 0, 0};
-      }
-#pragma unroll
-      for (uint32_t u = 0; u < kUnroll; ++u) {
-        const uint32_t i = base + u * kHistThreads + tid;
-        if (i < nvec) {
-          count(k[u][0]);
-          count(k[u][1]);
-          count(k[u][2]);
-          count(k[u][3]);
-        }
+    for (uint32_t u = 0; u < 4; ++u) {
+      if (group * kHistGroupVecs + u * kHistThreads + tid < nvec) {
+        count(k[u][0]);
+        count(k[u][1]);
+        count(k[u][2]);
+        count(k[u][3]);
       }
     }
   };
+
+  const uint32_t nvec = n >> 2;
+  const u32x4* keys4 = reinterpret_cast<const u32x4*>(keys);
+  const uint32_t groups = (nvec + kHistGroupVecs - 1) / kHistGroupVecs;
+  // Inputs of more than half the 256 MiB Infinity Cache are read with non-temporal loads (little of them
+  // would still be there for pass 0): 51 instead of 55 us at N = 2^26, 90 instead of 104 us at 2^27, no
+  // difference at 2^24 and 2^25 (profiles/r02_streaming_loads.txt).
+  auto sweep = [&](auto streaming) {
+    constexpr bool NT = decltype(streaming)::value;
+    uint32_t g = blockIdx.x;
+    const uint32_t end = groups;
+    const uint32_t step = gridDim.x;
+    u32x4 a[4], b[4];
+    // the first two groups' loads fly while the counters are cleared (nvec >= 1 here)
+    HistFetch<NT>(keys4, g, tid, nvec, a);
+    HistFetch<NT>(keys4, g + step, tid, nvec, b);
+    for (uint32_t i = tid; i < VRDX_PASSES * VRDX_RADIX * COPIES; i += kHistThreads) bins[i] = 0;
+    LdsBarrier();  // LDS only: the loads in flight are not waited for here
+    for (; g < end; g += 2 * step) {
+      tally(g, a, nvec);
+      HistFetch<NT>(keys4, g + 2 * step, tid, nvec, a);
+      if (g + step < end) tally(g + step, b, nvec);
+      HistFetch<NT>(keys4, g + 3 * step, tid, nvec, b);
+    }
+  };
   const bool streamingInput = VRDX_HIST_NT == 2 || (VRDX_HIST_NT == 1 && n > kHistStreamingLoadsAbove);
-  if (streamingInput) {
+  if (nvec == 0) {  // fewer than four keys
+    for (uint32_t i = tid; i < VRDX_PASSES * VRDX_RADIX * COPIES; i += kHistThreads) bins[i] = 0;
+    LdsBarrier();
+  } else if (streamingInput) {
     asm volatile("; non-temporal key loads" ::: "memory");  // keeps the two loops apart (see LoadTile)
     sweep(std::true_type{});
   } else {
@@ -381,6 +377,14 @@ __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t*
     for (uint32_t c = 0; c < COPIES; ++c) sum += bins[b * COPIES + ((c + tid) & (COPIES - 1))];
     if (sum != 0) atomicAdd(&globalHistogram[b], sum);
   }
+}
+
+// Sum over the four lanes of a quad (all lanes active), result in every lane.
+__device__ __forceinline__ uint32_t QuadSum(uint32_t v) {
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);  // quad_perm:[1,0,3,2]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);  // quad_perm:[2,3,0,1]
+  return (uint32_t)x;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -405,7 +409,6 @@ __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t*
 #define VRDX_LOOKBACK_WINDOW 8
 #endif
 constexpr int kLookBackWindow = VRDX_LOOKBACK_WINDOW;
-constexpr uint32_t kSpinLimit = 1u << 18;
 constexpr int32_t kLookBackDone = INT32_MIN;
 
 // One 16-byte store of a sorted quad to out[index .. index + 3] (4-byte aligned).
@@ -419,7 +422,8 @@ __device__ __forceinline__ void StoreQuad(uint32_t* out, uint32_t index, u32x4 q
 
 template <int THREADS>
 __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t tile, int tid, uint32_t* lds,
-                                             uint32_t* failure, uint32_t* stickyFailure, uint32_t* traceTripsRows) {
+                                             uint32_t* failure, uint32_t* stickyFailure, uint32_t spinLimit,
+                                             uint32_t* traceTripsRows) {
   constexpr int GROUPS = THREADS / 256;
   constexpr int W = kLookBackWindow;
   int32_t* const pos = reinterpret_cast<int32_t*>(lds);
@@ -481,7 +485,7 @@ __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t ti
         if ((in & 0xFFu) < (uint32_t)W) break;  // blocked on a tile that has not published yet
       }
       if (!done && advance == 0) {
-        if (++spins > kSpinLimit) {
+        if (++spins > spinLimit) {
           atomicOr(failure, 1u);  // bounded: give up (result unspecified) rather than hang the GPU
           if (stickyFailure != nullptr) atomicOr(stickyFailure, 1u);  // the sorter's word: survives the next sort's clear
           done = true;
@@ -526,15 +530,11 @@ __device__ __forceinline__ void RankBallot(const uint32_t (&key)[KPT], uint32_t 
 #pragma unroll
   for (int i = 0; i < KPT; ++i) {
     const uint32_t d = (key[i] >> shift) & 0xFFu;
-    const uint64_t same = (kAblate & 2u) ? (1ull << lane) : MatchDigit(d);
+    const uint64_t same = MatchDigit(d);
     const uint32_t below = LanesBelow(same);
-    uint32_t prior = 0;
-    if (!(kAblate & 16u)) {
-      prior = __hip_atomic_load(&myHist[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (below == 0)
-        __hip_atomic_fetch_add(&myHist[d], (uint32_t)__popcll(same), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+    const uint32_t prior = __hip_atomic_load(&myHist[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (below == 0)
+      __hip_atomic_fetch_add(&myHist[d], (uint32_t)__popcll(same), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     rank[i] = prior + below;
   }
 }
@@ -641,7 +641,6 @@ __device__ __forceinline__ void RegroupKeys(const uint32_t (&key)[KPT], const ui
       else
         r = rank[i];
       p[c] = StagingSlot<STAGE>(p[c] + r);
-      if (kAblate & (2u | 16u)) p[c] = (p[c] + i * 64) % STAGE;
       sorted[p[c]] = key[i];
       if constexpr (KEEP) {
         if (c % 2 == 1) {
@@ -692,13 +691,12 @@ __device__ __forceinline__ uint32_t BoundaryQuad(int tid, uint32_t myRunStart, u
 
 template <uint32_t STAGE>
 __device__ __forceinline__ void StoreBoundaryQuad(const uint32_t* sorted, const uint32_t* offset, uint32_t* out,
-                                                  uint32_t quad, uint32_t valid, uint32_t packedDigits,
-                                                  uint32_t linearBase) {
+                                                  uint32_t quad, uint32_t valid, uint32_t packedDigits) {
   const u32x4 q = *reinterpret_cast<const u32x4*>(&sorted[StagingSlot<STAGE>(quad)]);
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const uint32_t d = (packedDigits >> (8 * c)) & 0xFFu;
-    if (quad + c < valid) StoreWord(out, ((kAblate & (4u | 256u)) ? linearBase : offset[d]) + quad + c, q[c]);
+    if (quad + c < valid) StoreWord(out, offset[d] + quad + c, q[c]);
   }
 }
 
@@ -720,7 +718,7 @@ template <int THREADS, int KPT, bool KEEP_DIGITS>
 __device__ __forceinline__ void ScatterStagedKeys(const uint32_t* sorted, const uint32_t* offset, uint32_t* out,
                                                   uint32_t valid, uint32_t shift, int tid, uint32_t boundaryQuad,
                                                   uint32_t (&digits)[KEEP_DIGITS ? KPT / 4 : 1],
-                                                  uint32_t& boundaryDigits, uint32_t linearBase = 0) {
+                                                  uint32_t& boundaryDigits) {
   constexpr uint32_t STAGE = THREADS * KPT;
   constexpr int B = ScatterBatch<KPT, KEEP_DIGITS>();
 #pragma unroll
@@ -734,14 +732,8 @@ __device__ __forceinline__ void ScatterStagedKeys(const uint32_t* sorted, const 
     for (int b = 0; b < B; ++b) {
       const uint32_t p = StagingSlot<STAGE>(4u * (tid + (j0 + b) * THREADS));  // involution: the sorted position
       const uint32_t d0 = (k4[b][0] >> shift) & 0xFFu, d3 = (k4[b][3] >> shift) & 0xFFu;
-      whole[b] = (kAblate & 32u) || (p + 3 < valid && d0 == d3);
-      if (kAblate & 256u) {  // linear stores that still wait for their offset lookup
-        uint32_t looked = offset[d0];
-        asm volatile("v_and_b32 %0, 0, %0" : "+v"(looked));
-        o[b] = linearBase + p + looked;
-      } else {
-        o[b] = (kAblate & 4u) ? linearBase + p : offset[d0] + p;
-      }
+      whole[b] = p + 3 < valid && d0 == d3;
+      o[b] = offset[d0] + p;
       asm volatile("" : "+v"(o[b]));  // fetched here, for every quad: not sunk into the conditional store
       if (KEEP_DIGITS) digits[j0 + b] = d0 | (d3 << 8);
     }
@@ -749,19 +741,18 @@ __device__ __forceinline__ void ScatterStagedKeys(const uint32_t* sorted, const 
     for (int b = 0; b < B; ++b)
       if (whole[b]) StoreQuad(out, o[b], k4[b]);
   }
-  if (boundaryQuad != ~0u && !(kAblate & 128u)) {
+  if (boundaryQuad != ~0u) {
     const u32x4 k4 = *reinterpret_cast<const u32x4*>(&sorted[StagingSlot<STAGE>(boundaryQuad)]);
     boundaryDigits = ((k4[0] >> shift) & 0xFFu) | (((k4[1] >> shift) & 0xFFu) << 8) |
                      (((k4[2] >> shift) & 0xFFu) << 16) | (((k4[3] >> shift) & 0xFFu) << 24);
-    StoreBoundaryQuad<STAGE>(sorted, offset, out, boundaryQuad, valid, boundaryDigits, linearBase);
+    StoreBoundaryQuad<STAGE>(sorted, offset, out, boundaryQuad, valid, boundaryDigits);
   }
 }
 
 template <int THREADS, int KPT>
 __device__ __forceinline__ void ScatterStagedValues(const uint32_t* sorted, const uint32_t* offset, uint32_t* out,
                                                     uint32_t valid, int tid, uint32_t boundaryQuad,
-                                                    const uint32_t (&digits)[KPT / 4], uint32_t boundaryDigits,
-                                                    uint32_t linearBase = 0) {
+                                                    const uint32_t (&digits)[KPT / 4], uint32_t boundaryDigits) {
   constexpr uint32_t STAGE = THREADS * KPT;
   constexpr int B = ScatterBatch<KPT, false>();
 #pragma unroll
@@ -771,7 +762,7 @@ __device__ __forceinline__ void ScatterStagedValues(const uint32_t* sorted, cons
 #pragma unroll
     for (int b = 0; b < B; ++b) {
       const uint32_t p = StagingSlot<STAGE>(4u * (tid + (j0 + b) * THREADS));
-      o[b] = (kAblate & 4u) ? linearBase + p : offset[digits[j0 + b] & 0xFFu] + p;
+      o[b] = offset[digits[j0 + b] & 0xFFu] + p;
       v4[b] = *reinterpret_cast<const u32x4*>(&sorted[4u * (tid + (j0 + b) * THREADS)]);
       asm volatile("" : "+v"(o[b]));
     }
@@ -779,12 +770,12 @@ __device__ __forceinline__ void ScatterStagedValues(const uint32_t* sorted, cons
     for (int b = 0; b < B; ++b) {
       const uint32_t p = StagingSlot<STAGE>(4u * (tid + (j0 + b) * THREADS));
       const uint32_t d0 = digits[j0 + b] & 0xFFu, d3 = digits[j0 + b] >> 8;
-      if ((kAblate & 32u) || (p + 3 < valid && d0 == d3))
+      if (p + 3 < valid && d0 == d3)
         StoreQuad(out, o[b], v4[b]);
     }
   }
-  if (boundaryQuad != ~0u && !(kAblate & 128u))
-    StoreBoundaryQuad<STAGE>(sorted, offset, out, boundaryQuad, valid, boundaryDigits, linearBase);
+  if (boundaryQuad != ~0u)
+    StoreBoundaryQuad<STAGE>(sorted, offset, out, boundaryQuad, valid, boundaryDigits);
 }
 
 // Key+value tiles replay the permutation for the values through the SAME staging buffer after the
@@ -837,18 +828,11 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   uint64_t stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   VRDX_STAMP(0);
-  Dephase();
 
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   uint32_t key[KPT];
-  if (kAblate & 64u) {  // timing only: tile = blockIdx and the keys of the usual source requested at once
-    const uint32_t start = blockIdx.x * TILE;
-    if (start < n)
-      LoadStriped<KPT, false>((a.pass & 1u) ? a.keysScratch : a.keysCaller, start + wave * (KPT * 64) + lane, n,
-                              n - start >= TILE, 0xFFFFFFFFu, key);
-  }
   const PassCounts<THREADS> passCounts = LoadPassCounts<THREADS>(a.histogramTable, tid);
-  if (tid == 0) misc[0] = (kAblate & (8u | 64u)) ? blockIdx.x : atomicAdd(a.ticketCur, 1u);
+  if (tid == 0) misc[0] = atomicAdd(a.ticketCur, 1u);
   PublishPassVotes<THREADS>(passCounts, n, tid, planFlags);
   for (int i = tid; i < WAVES * 256; i += THREADS) waveHist[i] = 0;
   LdsBarrier();
@@ -891,7 +875,7 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   // highest memory positions of the tile and have digit 255 in every pass, so the stable ranking
   // puts them at tile-local positions >= valid, where nothing is written.
   const bool streaming = KV && StreamingLoads(KV, n);
-  if (!(kAblate & 64u)) LoadTile<KPT>(keysIn, loadBase, n, valid == TILE, 0xFFFFFFFFu, key, streaming);
+  LoadTile<KPT>(keysIn, loadBase, n, valid == TILE, 0xFFFFFFFFu, key, streaming);
   if (plan.copy) {  // identity permutation that has to change buffers: copy the tile
     StoreStriped<KPT>(keysOut, loadBase, n, valid == TILE, key);
     if constexpr (KV) {
@@ -956,8 +940,8 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
 
   // ---- decoupled look-back over the preceding tiles, then publish the inclusive prefix --------
   uint32_t lookBackTrace = 0;
-  if (tile != 0 && !(kAblate & 1u))
-    exclusive = LookBack<THREADS>(a.statusCur, tile, tid, waveHist, a.failure, a.stickyFailure, &lookBackTrace);
+  if (tile != 0)
+    exclusive = LookBack<THREADS>(a.statusCur, tile, tid, waveHist, a.failure, a.stickyFailure, a.spinLimit, &lookBackTrace);
   if (tid < 256) {
     if (!lastTile)
       StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid],
@@ -980,14 +964,14 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   uint32_t boundaryDigits = 0;
   const uint32_t boundaryQuad = BoundaryQuad(tid, tileExclusive, count, valid);
   ScatterStagedKeys<THREADS, KPT, KV>(sorted, tileOffset, keysOut, valid, shift, tid, boundaryQuad, digits,
-                                      boundaryDigits, tileStart);
+                                      boundaryDigits);
   if constexpr (KV) {
     LdsBarrier();  // every key has left the staging buffer
 #pragma unroll
     for (int i = 0; i < KPT; ++i) sorted[(packedPos[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
     LdsBarrier();
     ScatterStagedValues<THREADS, KPT>(sorted, tileOffset, valuesOut, valid, tid, boundaryQuad, digits,
-                                      boundaryDigits, tileStart);
+                                      boundaryDigits);
   }
 #ifdef VRDX_TRACE
   VRDX_STAMP(6);
@@ -1058,11 +1042,10 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
   uint64_t stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   VRDX_STAMP(0);
-  Dephase();
 
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   const PassCounts<THREADS> passCounts = LoadPassCounts<THREADS>(a.histogramTable, tid);
-  if (tid == 0) misc[0] = (kAblate & 8u) ? blockIdx.x : atomicAdd(a.ticketCur, 1u);
+  if (tid == 0) misc[0] = atomicAdd(a.ticketCur, 1u);
   PublishPassVotes<THREADS>(passCounts, n, tid, misc + 1);
   for (int i = tid; i < WAVES * 256; i += THREADS) waveHist[i] = 0;
   LdsBarrier();
@@ -1193,8 +1176,9 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
 
   // ---- one look-back for both sub-tiles ----------------------------------------------------------
   uint32_t lookBackTrace = 0;
-  if (tile != 0 && !(kAblate & 1u))
-    exclusive = LookBack<THREADS>(a.statusCur, tile, tid, lookScratch, a.failure, a.stickyFailure, &lookBackTrace);
+  if (tile != 0)
+    exclusive = LookBack<THREADS>(a.statusCur, tile, tid, lookScratch, a.failure, a.stickyFailure, a.spinLimit,
+                                  &lookBackTrace);
   if (tid < 256) {
     if (!lastTile)
       StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid],
@@ -1214,16 +1198,16 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
     uint32_t val[KPT];
     LoadStriped<KPT>(valuesIn, loadBaseA, n, validA == SUB, 0u, val);  // pad: downsweep.slang:85
     ScatterStagedKeys<THREADS, KPT, true>(sorted, offsetA, keysOut, validA, shift, tid, boundaryQuadA, digits,
-                                          boundaryDigits, tileStart);
+                                          boundaryDigits);
     LdsBarrier();
 #pragma unroll
     for (int i = 0; i < KPT; ++i) sorted[(packedPosA[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
     LdsBarrier();
     ScatterStagedValues<THREADS, KPT>(sorted, offsetA, valuesOut, validA, tid, boundaryQuadA, digits,
-                                      boundaryDigits, tileStart);
+                                      boundaryDigits);
   } else {
     ScatterStagedKeys<THREADS, KPT, false>(sorted, offsetA, keysOut, validA, shift, tid, boundaryQuadA, digits,
-                                           boundaryDigits, tileStart);
+                                           boundaryDigits);
   }
   LdsBarrier();  // the staging buffer is free again
 
@@ -1235,16 +1219,16 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
     uint32_t val[KPT];
     LoadStriped<KPT>(valuesIn, loadBaseB, n, validB == SUB, 0u, val);
     ScatterStagedKeys<THREADS, KPT, true>(sorted, offsetB, keysOut, validB, shift, tid, boundaryQuadB, digits,
-                                          boundaryDigits, tileStart + SUB);
+                                          boundaryDigits);
     LdsBarrier();
 #pragma unroll
     for (int i = 0; i < KPT; ++i) sorted[(packedPosB[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
     LdsBarrier();
     ScatterStagedValues<THREADS, KPT>(sorted, offsetB, valuesOut, validB, tid, boundaryQuadB, digits,
-                                      boundaryDigits, tileStart + SUB);
+                                      boundaryDigits);
   } else {
     ScatterStagedKeys<THREADS, KPT, false>(sorted, offsetB, keysOut, validB, shift, tid, boundaryQuadB, digits,
-                                           boundaryDigits, tileStart + SUB);
+                                           boundaryDigits);
   }
 #ifdef VRDX_TRACE
   VRDX_STAMP(6);
@@ -1419,6 +1403,23 @@ __global__ __launch_bounds__(1024) void lds_order_check_kernel(uint32_t* mismatc
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
+// Every launcher returns the hipError_t of ITS launch (hipLaunchKernel), so that the recorder never has to consult
+// the calling thread's sticky last-error state, which an unrelated earlier failure may have set.
+template <typename... Args>
+static hipError_t Launch(const void* kernel, uint32_t grid, uint32_t block, size_t ldsBytes, hipStream_t stream,
+                         Args... args) {
+  void* argv[] = {static_cast<void*>(&args)...};
+  return hipLaunchKernel(kernel, dim3(grid), dim3(block), argv, ldsBytes, stream);
+}
+
+template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK>
+static const void* OnesweepKernel() {
+  return reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, KV, ATOMIC_RANK>);
+}
+template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK>
+static const void* PairKernel() {
+  return reinterpret_cast<const void*>(&onesweep_pair_kernel<THREADS, KPT, KV, ATOMIC_RANK>);
+}
 
 template <int THREADS, int KPT>
 static hipError_t PrepareConfig() {
@@ -1428,10 +1429,10 @@ static hipError_t PrepareConfig() {
     const void* fn;
     int bytes;
   } kernels[4] = {
-      {reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, false, false>), keysBytes},
-      {reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, false, true>), keysBytes},
-      {reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, true, false>), kvBytes},
-      {reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, true, true>), kvBytes},
+      {OnesweepKernel<THREADS, KPT, false, false>(), keysBytes},
+      {OnesweepKernel<THREADS, KPT, false, true>(), keysBytes},
+      {OnesweepKernel<THREADS, KPT, true, false>(), kvBytes},
+      {OnesweepKernel<THREADS, KPT, true, true>(), kvBytes},
   };
   for (const auto& k : kernels) {
     const hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, k.bytes);
@@ -1441,33 +1442,24 @@ static hipError_t PrepareConfig() {
 }
 
 template <int THREADS, int KPT>
-static void LaunchConfig(hipStream_t stream, uint32_t grid, bool keyValue, bool atomicRank,
-                         const OnesweepArgs& args) {
+static hipError_t LaunchConfig(hipStream_t stream, uint32_t grid, bool keyValue, bool atomicRank,
+                               const OnesweepArgs& args) {
   const size_t lds = (keyValue ? OnesweepLdsWords<THREADS, KPT, true>() : OnesweepLdsWords<THREADS, KPT, false>()) *
                      sizeof(uint32_t);
-  const dim3 g(grid), b(THREADS);
-  if (keyValue) {
-    if (atomicRank)
-      hipLaunchKernelGGL((onesweep_kernel<THREADS, KPT, true, true>), g, b, lds, stream, args);
-    else
-      hipLaunchKernelGGL((onesweep_kernel<THREADS, KPT, true, false>), g, b, lds, stream, args);
-  } else {
-    if (atomicRank)
-      hipLaunchKernelGGL((onesweep_kernel<THREADS, KPT, false, true>), g, b, lds, stream, args);
-    else
-      hipLaunchKernelGGL((onesweep_kernel<THREADS, KPT, false, false>), g, b, lds, stream, args);
-  }
+  const void* const kernel =
+      keyValue ? (atomicRank ? OnesweepKernel<THREADS, KPT, true, true>() : OnesweepKernel<THREADS, KPT, true, false>())
+               : (atomicRank ? OnesweepKernel<THREADS, KPT, false, true>() : OnesweepKernel<THREADS, KPT, false, false>());
+  return Launch(kernel, grid, THREADS, lds, stream, args);
 }
 
+// The two-sub-tile kernel exists for keys-only sorts: its key+value form would hold sub-tile B's keys and
+// ranks, A's staging slots and A's values at once and spills (measured 40 GItems/s in round 1; a 768-thread
+// form with 168 registers and no spill measured 54.5 GItems/s against 67.2 for onesweep_kernel<1024, 32>,
+// profiles/r03_geometry.txt), so it is not built.
 template <int THREADS, int KPT>
 static hipError_t PreparePairConfig() {
   const int bytes = (int)(PairLdsWords<THREADS, KPT>() * sizeof(uint32_t));
-  const void* kernels[4] = {
-      reinterpret_cast<const void*>(&onesweep_pair_kernel<THREADS, KPT, false, false>),
-      reinterpret_cast<const void*>(&onesweep_pair_kernel<THREADS, KPT, false, true>),
-      reinterpret_cast<const void*>(&onesweep_pair_kernel<THREADS, KPT, true, false>),
-      reinterpret_cast<const void*>(&onesweep_pair_kernel<THREADS, KPT, true, true>),
-  };
+  const void* kernels[2] = {PairKernel<THREADS, KPT, false, false>(), PairKernel<THREADS, KPT, false, true>()};
   for (const void* fn : kernels) {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return e;
@@ -1476,21 +1468,12 @@ static hipError_t PreparePairConfig() {
 }
 
 template <int THREADS, int KPT>
-static void LaunchPairConfig(hipStream_t stream, uint32_t grid, bool keyValue, bool atomicRank,
-                             const OnesweepArgs& args) {
+static hipError_t LaunchPairConfig(hipStream_t stream, uint32_t grid, bool keyValue, bool atomicRank,
+                                   const OnesweepArgs& args) {
+  if (keyValue) return hipErrorInvalidValue;  // never selected (ConfigIndex)
   const size_t lds = PairLdsWords<THREADS, KPT>() * sizeof(uint32_t);
-  const dim3 g(grid), b(THREADS);
-  if (keyValue) {
-    if (atomicRank)
-      hipLaunchKernelGGL((onesweep_pair_kernel<THREADS, KPT, true, true>), g, b, lds, stream, args);
-    else
-      hipLaunchKernelGGL((onesweep_pair_kernel<THREADS, KPT, true, false>), g, b, lds, stream, args);
-  } else {
-    if (atomicRank)
-      hipLaunchKernelGGL((onesweep_pair_kernel<THREADS, KPT, false, true>), g, b, lds, stream, args);
-    else
-      hipLaunchKernelGGL((onesweep_pair_kernel<THREADS, KPT, false, false>), g, b, lds, stream, args);
-  }
+  return Launch(atomicRank ? PairKernel<THREADS, KPT, false, true>() : PairKernel<THREADS, KPT, false, false>(), grid,
+                THREADS, lds, stream, args);
 }
 
 // Every geometry here is selected by ConfigIndex (vrdx_api.cpp) for some size range; nothing else is built.
@@ -1499,13 +1482,18 @@ const TileConfig kTileConfigs[kNumTileConfigs] = {
 };
 
 hipError_t PrepareKernels(int configIndex) {
-  if (configIndex == 0) {  // once per sorter: the histogram kernel's dynamic LDS
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&histogram_kernel<kHistCopies>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)HistLdsBytes(kHistCopies));
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&histogram_kernel<kHistCopiesLarge>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)HistLdsBytes(kHistCopiesLarge));
-    if (e != hipSuccess) return e;
+  if (configIndex == 0) {  // once per sorter: the histogram kernels' dynamic LDS
+    const struct {
+      const void* fn;
+      uint32_t bytes;
+    } kernels[2] = {
+        {reinterpret_cast<const void*>(&histogram_kernel<kHistCopies>), HistLdsBytes(kHistCopies)},
+        {reinterpret_cast<const void*>(&histogram_kernel<kHistCopiesLarge>), HistLdsBytes(kHistCopiesLarge)},
+    };
+    for (const auto& k : kernels) {
+      const hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.bytes);
+      if (e != hipSuccess) return e;
+    }
   }
   switch (configIndex) {
     case 0: return PrepareConfig<1024, 8>();
@@ -1522,26 +1510,29 @@ hipError_t LdsOrderCheck(bool* laneOrdered) {
   if (e != hipSuccess) return e;
   uint32_t h = 0xFFFFFFFFu;
   e = hipMemset(d, 0, sizeof(uint32_t));
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(lds_order_check_kernel, dim3(512), dim3(1024), 0, nullptr, d);
-    e = hipMemcpy(&h, d, sizeof(uint32_t), hipMemcpyDeviceToHost);
-  }
+  if (e == hipSuccess) e = Launch(reinterpret_cast<const void*>(&lds_order_check_kernel), 512, 1024, 0, nullptr, d);
+  if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof(uint32_t), hipMemcpyDeviceToHost);
   (void)hipFree(d);
   if (e == hipSuccess) *laneOrdered = h == 0;
   return e;
 }
 
 // ---- single-launch path for small sorts ---------------------------------------------------------
+template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK>
+static const void* SmallKernel() {
+  return reinterpret_cast<const void*>(&small_sort_kernel<THREADS, KPT, KV, ATOMIC_RANK>);
+}
+
 template <int THREADS, int KPT>
 static hipError_t PrepareSmall() {
   const struct {
     const void* fn;
     size_t words;
   } kernels[4] = {
-      {reinterpret_cast<const void*>(&small_sort_kernel<THREADS, KPT, false, false>), SmallSortLdsWords<THREADS, KPT, false>()},
-      {reinterpret_cast<const void*>(&small_sort_kernel<THREADS, KPT, false, true>), SmallSortLdsWords<THREADS, KPT, false>()},
-      {reinterpret_cast<const void*>(&small_sort_kernel<THREADS, KPT, true, false>), SmallSortLdsWords<THREADS, KPT, true>()},
-      {reinterpret_cast<const void*>(&small_sort_kernel<THREADS, KPT, true, true>), SmallSortLdsWords<THREADS, KPT, true>()},
+      {SmallKernel<THREADS, KPT, false, false>(), SmallSortLdsWords<THREADS, KPT, false>()},
+      {SmallKernel<THREADS, KPT, false, true>(), SmallSortLdsWords<THREADS, KPT, false>()},
+      {SmallKernel<THREADS, KPT, true, false>(), SmallSortLdsWords<THREADS, KPT, true>()},
+      {SmallKernel<THREADS, KPT, true, true>(), SmallSortLdsWords<THREADS, KPT, true>()},
   };
   for (const auto& k : kernels) {
     const hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(k.words * 4));
@@ -1551,22 +1542,14 @@ static hipError_t PrepareSmall() {
 }
 
 template <int THREADS, int KPT>
-static void LaunchSmall(hipStream_t stream, bool atomicRank, uint32_t* keys, uint32_t* values, uint32_t maxCount,
-                        const uint32_t* countPtr, uint32_t* failure) {
-  const dim3 g(1), b(THREADS);
-  if (values != nullptr) {
-    const size_t lds = SmallSortLdsWords<THREADS, KPT, true>() * 4;
-    if (atomicRank)
-      hipLaunchKernelGGL((small_sort_kernel<THREADS, KPT, true, true>), g, b, lds, stream, keys, values, maxCount, countPtr, failure);
-    else
-      hipLaunchKernelGGL((small_sort_kernel<THREADS, KPT, true, false>), g, b, lds, stream, keys, values, maxCount, countPtr, failure);
-  } else {
-    const size_t lds = SmallSortLdsWords<THREADS, KPT, false>() * 4;
-    if (atomicRank)
-      hipLaunchKernelGGL((small_sort_kernel<THREADS, KPT, false, true>), g, b, lds, stream, keys, values, maxCount, countPtr, failure);
-    else
-      hipLaunchKernelGGL((small_sort_kernel<THREADS, KPT, false, false>), g, b, lds, stream, keys, values, maxCount, countPtr, failure);
-  }
+static hipError_t LaunchSmall(hipStream_t stream, bool atomicRank, uint32_t* keys, uint32_t* values, uint32_t maxCount,
+                              const uint32_t* countPtr, uint32_t* failure) {
+  const bool keyValue = values != nullptr;
+  const size_t lds = (keyValue ? SmallSortLdsWords<THREADS, KPT, true>() : SmallSortLdsWords<THREADS, KPT, false>()) * 4;
+  const void* const kernel =
+      keyValue ? (atomicRank ? SmallKernel<THREADS, KPT, true, true>() : SmallKernel<THREADS, KPT, true, false>())
+               : (atomicRank ? SmallKernel<THREADS, KPT, false, true>() : SmallKernel<THREADS, KPT, false, false>());
+  return Launch(kernel, 1, THREADS, lds, stream, keys, values, maxCount, countPtr, failure);
 }
 
 hipError_t PrepareSmallSort() {
@@ -1575,32 +1558,29 @@ hipError_t PrepareSmallSort() {
   return e;
 }
 
-void LaunchSmallSort(hipStream_t stream, bool atomicRank, uint32_t* keys, uint32_t* values, uint32_t maxCount,
-                     const uint32_t* countPtr, uint32_t* failure) {
-  if (maxCount <= 256u * 16u)
-    LaunchSmall<256, 16>(stream, atomicRank, keys, values, maxCount, countPtr, failure);
-  else
-    LaunchSmall<1024, 16>(stream, atomicRank, keys, values, maxCount, countPtr, failure);
+hipError_t LaunchSmallSort(hipStream_t stream, bool atomicRank, uint32_t* keys, uint32_t* values, uint32_t maxCount,
+                           const uint32_t* countPtr, uint32_t* failure) {
+  if (maxCount <= 256u * 16u) return LaunchSmall<256, 16>(stream, atomicRank, keys, values, maxCount, countPtr, failure);
+  return LaunchSmall<1024, 16>(stream, atomicRank, keys, values, maxCount, countPtr, failure);
 }
 
-void LaunchHistogram(hipStream_t stream, uint32_t grid, const uint32_t* keys, uint32_t maxCount,
-                     const uint32_t* countPtr, uint32_t* globalHistogram, uint32_t* tickets) {
+hipError_t LaunchHistogram(hipStream_t stream, uint32_t grid, const uint32_t* keys, uint32_t maxCount,
+                           const uint32_t* countPtr, uint32_t* globalHistogram, uint32_t* tickets) {
   if (maxCount >= kHistManyCopiesFrom)
-    hipLaunchKernelGGL(histogram_kernel<kHistCopiesLarge>, dim3(grid), dim3(kHistThreads),
-                       HistLdsBytes(kHistCopiesLarge), stream, keys, maxCount, countPtr, globalHistogram, tickets);
-  else
-    hipLaunchKernelGGL(histogram_kernel<kHistCopies>, dim3(grid), dim3(kHistThreads), HistLdsBytes(kHistCopies),
-                       stream, keys, maxCount, countPtr, globalHistogram, tickets);
+    return Launch(reinterpret_cast<const void*>(&histogram_kernel<kHistCopiesLarge>), grid, kHistThreads,
+                  HistLdsBytes(kHistCopiesLarge), stream, keys, maxCount, countPtr, globalHistogram, tickets);
+  return Launch(reinterpret_cast<const void*>(&histogram_kernel<kHistCopies>), grid, kHistThreads,
+                HistLdsBytes(kHistCopies), stream, keys, maxCount, countPtr, globalHistogram, tickets);
 }
 
-void LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool keyValue, bool atomicRank,
-                    const OnesweepArgs& args) {
+hipError_t LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool keyValue, bool atomicRank,
+                          const OnesweepArgs& args) {
   switch (configIndex) {
-    case 0: LaunchConfig<1024, 8>(stream, grid, keyValue, atomicRank, args); break;
-    case 1: LaunchConfig<1024, 16>(stream, grid, keyValue, atomicRank, args); break;
-    case 2: LaunchConfig<1024, 32>(stream, grid, keyValue, atomicRank, args); break;
-    case 3: LaunchPairConfig<1024, 32>(stream, grid, keyValue, atomicRank, args); break;
-    default: break;
+    case 0: return LaunchConfig<1024, 8>(stream, grid, keyValue, atomicRank, args);
+    case 1: return LaunchConfig<1024, 16>(stream, grid, keyValue, atomicRank, args);
+    case 2: return LaunchConfig<1024, 32>(stream, grid, keyValue, atomicRank, args);
+    case 3: return LaunchPairConfig<1024, 32>(stream, grid, keyValue, atomicRank, args);
+    default: return hipErrorInvalidValue;
   }
 }
 
