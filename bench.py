@@ -48,20 +48,39 @@ def parse_args():
     return p.parse_args()
 
 
+def reference_stream(seed, n):
+    """SURVEY.md section 8(d), configs 2/3: keys = the first n raw outputs of std::mt19937(seed), values = the next n
+    (bench/data_generator.cc:20-25 under libstdc++).  numpy's legacy RandomState seeds MT19937 with init_genrand(seed)
+    like std::mt19937 does and hands out the raw 32-bit words for the full range (checked against the reference's
+    generator by tests/test_oracle.py::test_bench_input_stream_is_the_reference_generator)."""
+    import numpy as np
+    raw = np.random.RandomState(seed).randint(0, 1 << 32, size=2 * n, dtype=np.uint64).astype(np.uint32)
+    return raw[:n], raw[n:]
+
+
+def to_device(torch, a, device):
+    import numpy as np
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(device)
+
+
 def random_u32(torch, n, seed, device):
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    # uniform over the full 32-bit range, stored as int32 bit patterns
-    return torch.randint(-(1 << 31), 1 << 31, (n,), generator=g, device=device, dtype=torch.int64).to(torch.int32)
+    """Keys only: the reference stream of that seed, resident on the device."""
+    return to_device(torch, reference_stream(seed, n)[0], device)
 
 
 def timed_sorts(torch, dist, executor, n, steps, warmup, key_value, device, distributed):
     """Returns (wall_seconds_for_K_steps_max_over_ranks, per-step gpu ms list of this rank).
     Every sort goes through the batched front end's per-GPU executor (one array per step and rank)."""
     total = warmup + 2 * steps   # warm-up | the K timed steps | K more, each bracketed by events
-    seed0 = 1000 * (int(os.environ.get("RANK", "0")) + 1)
-    keys = [random_u32(torch, n, seed0 + i, device) for i in range(total)]
-    values = [random_u32(torch, n, seed0 + 500 + i, device) for i in range(total)] if key_value else None
+    # seeds 1, 2, ... like the reference's runs (bench/bench.cc:83-84); other ranks continue the sequence
+    seed0 = 1 + total * int(os.environ.get("RANK", "0"))
+    keys, values = [], ([] if key_value else None)
+    for i in range(total):
+        k, v = reference_stream(seed0 + i, n)
+        keys.append(to_device(torch, k, device))
+        if key_value:
+            values.append(to_device(torch, v, device))
+        del k, v
 
     def one(i):
         executor.enqueue([(keys[i], values[i] if key_value else None)])  # vrdxCmdSort[KeyValue]: never blocks
@@ -96,7 +115,8 @@ def timed_sorts(torch, dist, executor, n, steps, warmup, key_value, device, dist
     per_step_ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]
     status = executor.finish()  # the sorter's sticky word: every sort above, not only the last one
     if status != 0:
-        raise RuntimeError(f"device failure word {status}: look-back spin expired")
+        from vulkan_radix_sort_amd.batched import describe_status
+        raise RuntimeError(f"sorter status 0x{status:08x}: {describe_status(status)}")
     # the last step's output must be sorted (cheap sanity check outside the timed region)
     k = keys[-1].view(torch.int32).to(torch.int64) & 0xFFFFFFFF
     if not bool((k[1:] >= k[:-1]).all()):
@@ -116,8 +136,9 @@ def stage_profile(torch, sorter, n, key_value, device, repeats=5):
     pool = vrdx.QueryPool(15)
     hist, sweep = [], []
     for r in range(repeats + 1):
-        keys = random_u32(torch, n, 77 + r, device)
-        values = random_u32(torch, n, 177 + r, device) if key_value else None
+        k, v = reference_stream(77 + r, n)
+        keys = to_device(torch, k, device)
+        values = to_device(torch, v, device) if key_value else None
         torch.cuda.synchronize()
         if key_value:
             sorter.cmd_sort_key_value(stream, n, keys.data_ptr(), 0, values.data_ptr(), 0, storage.data_ptr(), 0,
@@ -195,6 +216,25 @@ def latest_pmc_traffic(version):
     return pmc
 
 
+def committed_rocprof_averages():
+    """Per-kernel average durations (us) of the rocprofv3 --kernel-trace --stats run of THIS command committed under
+    profiles/ (the newest rNN_rocprofv3_kernel_stats.csv), so that the event-timed figures of this line can be
+    compared with the profiler's from the JSON alone.  None when no such file is there."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_kernel_stats.csv")))
+    if not files:
+        return None
+    rows = {}
+    with open(files[-1]) as f:
+        for row in csv.DictReader(f):
+            if "vrdx::" in row["Name"] and "lds_order_check" not in row["Name"]:
+                name = row["Name"].replace("void vrdx::", "").split("(")[0]
+                rows[name] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3,
+                              "min_us": float(row["MinNs"]) / 1e3, "max_us": float(row["MaxNs"]) / 1e3}
+    return {"file": os.path.relpath(files[-1], ROOT), "kernels": rows}
+
+
 def kernel_source_digest():
     import hashlib
     h = hashlib.sha256()
@@ -206,15 +246,12 @@ def kernel_source_digest():
 
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks (torch.distributed.run) as a CHILD
-    process -- nothing in this process has touched a GPU yet, and nothing will -- and exit with the
-    child's code.  (Never exec from a process that holds a GPU context.)"""
+    process -- this process imports neither torch nor the HIP library, so it never touches a GPU -- and exit
+    with the child's code.  (Never exec from a process that holds a GPU context.)"""
     import socket
     import subprocess
-    import torch
-    have = torch.cuda.device_count()  # does not initialise the runtime
-    if have < args.gpus:
-        print(f"[bench] --gpus {args.gpus} but this node exposes {have} GPU(s)", file=sys.stderr)
-        return 2
+    # (no GPU query here, not even a device count: whatever the launched ranks find is checked by the ranks
+    # themselves -- a world size that differs from --gpus is exit code 2, see main())
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -294,6 +331,9 @@ def main():
                       "whole_sort_frac": KV_BYTES_PER_ITEM * n / (med_kv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
     }
 
+    rocprof = committed_rocprof_averages()
+    if rocprof:
+        roofline["rocprof"] = rocprof
     # counter-measured HBM bytes of the same kernels (profiles/pmc_traffic.json, only while its stamp matches this
     # library) over the launch duration measured above: the "measured HBM GB/s" beside the algorithmic figure
     if pmc:
@@ -309,7 +349,8 @@ def main():
         "metric": "GItems/s at N=2^25 (keys & key+value); achieved HBM GB/s vs peak",
         "value": value_keys, "unit": "GItems/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall_keys / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "u32",
+        "data": "synthetic: raw std::mt19937(seed) outputs, seeds 1.. (keys = first N, values = next N; SURVEY 8d)",
         "config": {"workload": f"N=2^{args.log2n} uniform-random u32 keys-only, 1xMI355X per rank "
                                f"(BASELINE.json configs[1]); key+value (configs[2]) under key_value",
                    "n": n, "arrays_per_step_per_gpu": 1,

@@ -140,3 +140,19 @@ def test_host_code_under_address_and_ub_sanitizers(tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "0 failures" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_no_kernel_uses_scratch_memory():
+    """A spill is not an option on this path (120 bytes of scratch per lane made a pass 30x slower, DESIGN.md section
+    4.2): the compiler's resource report (make resources) must show ScratchSize 0 for EVERY kernel of the code object,
+    the ballot-ranking forms included -- whichever ranking mode vrdxCreateSorter selects, no selectable kernel spills."""
+    import re
+    import subprocess
+    out = subprocess.run(["make", "-C", os.path.join(ROOT, "vulkan_radix_sort_amd", "csrc"), "resources"],
+                         capture_output=True, text=True, timeout=900)
+    report = out.stdout + out.stderr
+    names = re.findall(r"Function Name: (\S+)", report)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", report)]
+    assert len(names) >= 20 and len(names) == len(scratch), report[-2000:]
+    spilled = [(n, s) for n, s in zip(names, scratch) if s != 0]
+    assert not spilled, spilled

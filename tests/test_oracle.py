@@ -6,8 +6,12 @@
    the GPU box), on randomized inputs;
 3. against the storage-size table of SURVEY.md section 8(a3).
 """
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_storage_sizes_match_golden_table(oracle, golden):
@@ -140,3 +144,20 @@ def test_oracle_matches_reference_build(oracle, reference):
         sk, sv, _ = oracle.sort(k, v)
         rsk, rsv, _ = reference.sort_key_value(k, v)
         assert np.array_equal(sk, rsk) and np.array_equal(sv, rsv)
+
+
+def test_bench_input_stream_is_the_reference_generator(oracle, reference):
+    """bench.py generates its inputs itself (it may touch the oracle only in its cpu_baseline leg): its stream must be
+    the reference generator's -- keys = the first N raw mt19937(seed) outputs, values = the next N
+    (bench/data_generator.cc:20-25)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for seed, n in ((1, 1000), (42, 4097), (7, 65539)):
+        k, v = bench.reference_stream(seed, n)
+        ok, ov = oracle.generate(seed, n, 32)
+        assert k.dtype == np.uint32 and np.array_equal(k, ok) and np.array_equal(v, ov)
+        if reference is not None:
+            rk, rv = reference.generate(seed, n, 32)
+            assert np.array_equal(k, rk) and np.array_equal(v, rv)

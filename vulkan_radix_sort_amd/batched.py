@@ -52,6 +52,7 @@ class HipShardExecutor:
         self.device = torch.cuda.current_device() if device is None else int(device)
         self.sorter = Sorter(self.device)
         self._storage = None
+        self._streams = []  # every stream sorts were enqueued on since the last finish()
 
     def _storage_for(self, nbytes: int):
         if self._storage is None or self._storage.numel() < nbytes:
@@ -70,7 +71,10 @@ class HipShardExecutor:
         """arrays: (keys_tensor, values_tensor_or_None) pairs resident on this GPU (int32/uint32
         storage, sorted in place as uint32).  Returns the number of elements enqueued."""
         torch = self.torch
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        current = torch.cuda.current_stream(self.device)
+        stream = current.cuda_stream
+        if all(st.cuda_stream != stream for st in self._streams):
+            self._streams.append(current)
         need, items = 16, 0
         for keys, values in arrays:
             self._check(keys, "keys")
@@ -94,9 +98,13 @@ class HipShardExecutor:
         return items
 
     def finish(self) -> int:
-        """Waits for everything enqueued; returns the OR of the failure bits of all of it (0 = ok)."""
-        stream = self.torch.cuda.current_stream(self.device).cuda_stream
-        return self.sorter.read_sorter_status(stream)
+        """Waits for everything enqueued -- on the stream(s) it was enqueued on, whatever the current stream is by
+        now -- and returns the OR of the failure bits of all of it (0 = ok; ``describe_status`` names the bits)."""
+        streams = self._streams or [self.torch.cuda.current_stream(self.device)]
+        self._streams = []
+        for st in streams[:-1]:
+            st.synchronize()
+        return self.sorter.read_sorter_status(streams[-1].cuda_stream)
 
     def __call__(self, arrays: Sequence[tuple]) -> int:
         self.enqueue(arrays)
@@ -104,6 +112,22 @@ class HipShardExecutor:
 
     def close(self):
         self.sorter.destroy()
+
+
+def describe_status(word: int) -> str:
+    """The two independent diagnoses of vrdxHipReadSorterStatus: bit 0 = a look-back gave up on the DEVICE (bounded
+    spin expired, the result of that sort is unspecified); bit 31 = the RUNTIME refused an enqueue of a sort (fill,
+    copy or kernel launch) on the host side, i.e. that sort never ran as recorded."""
+    if word == 0:
+        return "ok"
+    if word == 0xFFFFFFFF:
+        return "status unreadable (the read-back itself failed)"
+    parts = []
+    if word & 0x80000000:
+        parts.append("an enqueue was refused by the HIP runtime (bit 31)")
+    if word & 0x7FFFFFFF:
+        parts.append("a device-side look-back spin expired (0x%x)" % (word & 0x7FFFFFFF))
+    return "; ".join(parts)
 
 
 class BatchedSorter:

@@ -397,8 +397,13 @@ VkResult vrdxCreateSorter(const VrdxSorterCreateInfo* pCreateInfo, VrdxSorter* p
       bool ordered = false;
       e = vrdx::LdsOrderCheck(&ordered);
       sorter->atomicRank = ordered;
-      if (e == hipSuccess && !ordered && mode != nullptr && std::strcmp(mode, "atomic") == 0)
-        std::fprintf(stderr, "vrdx-hip: VRDX_RANK=atomic refused, LDS atomics are not lane-ordered here\n");
+      if (e == hipSuccess && !ordered) {
+        // Never silent: the ballot form is correct everywhere but 2-3x slower.
+        std::fprintf(stderr,
+                     "vrdx-hip: LDS returning atomics are not lane-ordered on device %d: ranking with wave ballots "
+                     "instead (same results, about 2-3x slower)%s\n",
+                     ordinal, mode != nullptr && std::strcmp(mode, "atomic") == 0 ? "; VRDX_RANK=atomic refused" : "");
+      }
     }
   }
   (void)hipSetDevice(previous);

@@ -524,9 +524,12 @@ __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t ti
 //
 // Counters are wave-private and LDS serves one wave's operations in program order, so the add of
 // slot i is visible to slot i + 1 without any barrier.
-template <int KPT>
+// PACKED: ranks (< 64 * KPT <= 65536) are written two to a register, out[i / 2] bits 16*(i % 2).
+template <int KPT, bool PACKED = false>
 __device__ __forceinline__ void RankBallot(const uint32_t (&key)[KPT], uint32_t shift, uint32_t* myHist,
-                                           int lane, uint32_t (&rank)[KPT]) {
+                                           int lane, uint32_t (&out)[PACKED ? KPT / 2 : KPT]) {
+  static_assert(!PACKED || KPT % 2 == 0, "whole pairs");
+  uint32_t even = 0;
 #pragma unroll
   for (int i = 0; i < KPT; ++i) {
     const uint32_t d = (key[i] >> shift) & 0xFFu;
@@ -535,7 +538,17 @@ __device__ __forceinline__ void RankBallot(const uint32_t (&key)[KPT], uint32_t 
     const uint32_t prior = __hip_atomic_load(&myHist[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (below == 0)
       __hip_atomic_fetch_add(&myHist[d], (uint32_t)__popcll(same), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    rank[i] = prior + below;
+    const uint32_t r = prior + below;
+    if constexpr (PACKED) {
+      if (i % 2 == 0) {
+        even = r;
+      } else {
+        out[i / 2] = even | (r << 16);
+        asm volatile("" : "+v"(out[i / 2]));  // pack now, not when first used
+      }
+    } else {
+      out[i] = r;
+    }
   }
 }
 
@@ -889,13 +902,13 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   // key+value: ranks / positions live until the values are staged, so they are kept packed two to
   // a register (< TILE <= 65536) -- two workgroups per CU must fit the register file with no spill
   // at all (measured: 120 bytes of scratch per lane made a pass 30x slower).
-  constexpr bool PACKED = KV && ATOMIC_RANK;
+  constexpr bool PACKED = KV;
   static_assert(!KV || TILE <= 65536, "packed 16-bit positions");
   uint32_t rank[PACKED ? KPT / 2 : KPT];
   if constexpr (ATOMIC_RANK)
     RankAtomic<KPT, PACKED>(key, shift, waveHist + wave * 256, lane, rank);
   else
-    RankBallot<KPT>(key, shift, waveHist + wave * 256, lane, rank);
+    RankBallot<KPT, PACKED>(key, shift, waveHist + wave * 256, lane, rank);
   ForgetDerivedValues<KPT>(key);
   // key+value, early form: the values start their trip now and land during the scan and the regroup
   if constexpr (KV) {
@@ -1078,7 +1091,8 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
     if (tile == 0 && tid == 0) *a.ticketNext = 0;
   }
 
-  constexpr bool PACKED = ATOMIC_RANK;  // ranks and positions < SUB <= 65536, two to a register
+  static_assert(ATOMIC_RANK, "the two-sub-tile kernel exists with the one-atomic ranking only (ConfigIndex)");
+  constexpr bool PACKED = true;  // ranks and positions < SUB <= 65536, two to a register
   const uint32_t loadBaseA = tileStart + wave * (KPT * 64) + lane;
   const uint32_t loadBaseB = loadBaseA + SUB;
   uint32_t* const myHist = waveHist + wave * 256;
@@ -1099,10 +1113,7 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
     return;
   }
   uint32_t rankA[PACKED ? KPT / 2 : KPT];
-  if constexpr (ATOMIC_RANK)
-    RankAtomic<KPT, PACKED>(keyA, shift, myHist, lane, rankA);
-  else
-    RankBallot<KPT>(keyA, shift, myHist, lane, rankA);
+  RankAtomic<KPT, PACKED>(keyA, shift, myHist, lane, rankA);
   ForgetDerivedValues<KPT>(keyA);
 
   // ---- sub-tile B's keys start their trip now ---------------------------------------------------
@@ -1144,10 +1155,7 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
   for (int i = 0; i < 4; ++i) myHist[lane + 64 * i] = 0;
 
   uint32_t rankB[PACKED ? KPT / 2 : KPT];
-  if constexpr (ATOMIC_RANK)
-    RankAtomic<KPT, PACKED>(keyB, shift, myHist, lane, rankB);
-  else
-    RankBallot<KPT>(keyB, shift, myHist, lane, rankB);
+  RankAtomic<KPT, PACKED>(keyB, shift, myHist, lane, rankB);
   ForgetDerivedValues<KPT>(keyB);
   LdsBarrier();
   VRDX_STAMP(3);
@@ -1370,21 +1378,13 @@ __global__ __launch_bounds__(1024) void lds_order_check_kernel(uint32_t* mismatc
     for (int i = 0; i < 8; ++i) bad += ra[i] != rb[i];
   }
   // the counters keep counting (both sets alike), so the ranks below stay under 2^16: 64 lanes x (64 + 64) slots.
-  // The reference ranks are packed two to a register before the atomic ones are taken (register budget).
+  // The reference ranks come packed two to a register (register budget).
 #pragma unroll 1
   for (uint32_t form = 0; form < 2; ++form) {
     uint32_t key[32], want[16];
 #pragma unroll
     for (int i = 0; i < 32; ++i) key[i] = OrderCheckKey(tid, wave, 64 + 32 * form + i);
-    {
-      uint32_t rb[32];
-      RankBallot<32>(key, 0, histB, lane, rb);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        want[i] = rb[2 * i] | (rb[2 * i + 1] << 16);
-        asm volatile("" : "+v"(want[i]));
-      }
-    }
+    RankBallot<32, true>(key, 0, histB, lane, want);
     if (form == 0) {
       uint32_t ra[32];
       RankAtomic<32, false>(key, 0, histA, lane, ra);
@@ -1452,28 +1452,23 @@ static hipError_t LaunchConfig(hipStream_t stream, uint32_t grid, bool keyValue,
   return Launch(kernel, grid, THREADS, lds, stream, args);
 }
 
-// The two-sub-tile kernel exists for keys-only sorts: its key+value form would hold sub-tile B's keys and
+// The two-sub-tile kernel exists for keys-only sorts with the one-atomic ranking (the ballot form of it spills
+// 152 bytes per lane and ConfigIndex never selected it): its key+value form would hold sub-tile B's keys and
 // ranks, A's staging slots and A's values at once and spills (measured 40 GItems/s in round 1; a 768-thread
 // form with 168 registers and no spill measured 54.5 GItems/s against 67.2 for onesweep_kernel<1024, 32>,
 // profiles/r03_geometry.txt), so it is not built.
 template <int THREADS, int KPT>
 static hipError_t PreparePairConfig() {
   const int bytes = (int)(PairLdsWords<THREADS, KPT>() * sizeof(uint32_t));
-  const void* kernels[2] = {PairKernel<THREADS, KPT, false, false>(), PairKernel<THREADS, KPT, false, true>()};
-  for (const void* fn : kernels) {
-    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return e;
-  }
-  return hipSuccess;
+  return hipFuncSetAttribute(PairKernel<THREADS, KPT, false, true>(), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 template <int THREADS, int KPT>
 static hipError_t LaunchPairConfig(hipStream_t stream, uint32_t grid, bool keyValue, bool atomicRank,
                                    const OnesweepArgs& args) {
-  if (keyValue) return hipErrorInvalidValue;  // never selected (ConfigIndex)
+  if (keyValue || !atomicRank) return hipErrorInvalidValue;  // never selected (ConfigIndex)
   const size_t lds = PairLdsWords<THREADS, KPT>() * sizeof(uint32_t);
-  return Launch(atomicRank ? PairKernel<THREADS, KPT, false, true>() : PairKernel<THREADS, KPT, false, false>(), grid,
-                THREADS, lds, stream, args);
+  return Launch(PairKernel<THREADS, KPT, false, true>(), grid, THREADS, lds, stream, args);
 }
 
 // Every geometry here is selected by ConfigIndex (vrdx_api.cpp) for some size range; nothing else is built.
