@@ -11,7 +11,8 @@
 extern "C" uint64_t vrdx_oracle_storage_size(uint32_t n, uint32_t align, int key_value);
 
 int main() {
-  const uint32_t tileSizes[] = {8192, 10240, 12288, 14336, 16384, 32768, 65536};
+  // the kernels' capacities and strides in between (tiles start a multiple of 256 keys >= 8192 apart, PlanTiles)
+  const uint32_t tileSizes[] = {8192, 8448, 10240, 12288, 14336, 16384, 23808, 32768, 35840, 49408, 65536};
   uint64_t cases = 0;
   int failures = 0;
   auto check = [&](uint32_t n) {
