@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <numeric>
 #include <random>
+#include <unordered_map>
 #include <vector>
 
 #include "../include/vk_radix_sort.h"
@@ -171,7 +172,16 @@ int RunBatched(int devices, int arrays, int log2n, bool verify) {
   std::printf("  aggregate: %.3f GItems/s by the slowest GPU's device time, %.3f GItems/s by host wall time (%.3f ms)\n",
               slowest ? double(arrays) * n / double(slowest) : 0.0, double(arrays) * n / wallNs, wallNs / 1e6);
 
-  if (verify) {  // every array: ascending keys and an intact multiset of pairs; array 0 of every GPU: the reference's predicate
+  if (verify) {
+    // Every array: ascending keys, an intact multiset of (key, value) PAIRS -- a per-pair hash, so that values swapped
+    // between two pairs change the sum -- and stability: among equal keys the values keep their input order, which
+    // is checked against the order in which the input holds that key's values.  Array 0 of every GPU in addition:
+    // the reference's own predicate (bench/bench.cc:41-64), element by element against the cpu backend.
+    auto pairHash = [](uint32_t key, uint32_t value) {
+      uint64_t x = (uint64_t(key) << 32) | value;
+      x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull; x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull; x ^= x >> 33;
+      return x;
+    };
     std::unique_ptr<BenchmarkBase> cpu = CreateBenchmark("cpu");
     for (int g = 0; g < devices; ++g) {
       Device& dev = gpu[size_t(g)];
@@ -184,10 +194,30 @@ int RunBatched(int devices, int arrays, int log2n, bool verify) {
         bool ok = std::is_sorted(k.begin(), k.end());
         uint64_t sumBefore = 0, sumAfter = 0;
         for (uint32_t j = 0; j < n; ++j) {
-          sumBefore += uint64_t(keys[size_t(i)][j]) * 0x9E3779B97F4A7C15ull + values[size_t(i)][j];
-          sumAfter += uint64_t(k[j]) * 0x9E3779B97F4A7C15ull + v[j];
+          sumBefore += pairHash(keys[size_t(i)][j], values[size_t(i)][j]);
+          sumAfter += pairHash(k[j], v[j]);
         }
         ok = ok && sumBefore == sumAfter;
+        if (ok) {
+          // stability: the values of every run of equal keys, in output order, must be the input's values of that
+          // key in input order (uniform 32-bit keys: ~n^2 / 2^33 short runs).  One pass over the output collects the
+          // duplicated keys, one pass over the input replays their values in input order.
+          std::unordered_map<uint32_t, std::pair<uint32_t, uint32_t>> runs;  // key -> (next output index, end of its run)
+          for (uint32_t j = 0; j + 1 < n; ++j) {
+            if (k[j] != k[j + 1]) continue;
+            uint32_t end = j + 1;
+            while (end < n && k[end] == k[j]) ++end;
+            runs.emplace(k[j], std::make_pair(j, end));
+            j = end - 1;
+          }
+          for (uint32_t q = 0; ok && q < n; ++q) {
+            const auto it = runs.find(keys[size_t(i)][q]);
+            if (it == runs.end()) continue;
+            ok = it->second.first < it->second.second && v[it->second.first] == values[size_t(i)][q];
+            ++it->second.first;
+          }
+          for (const auto& r : runs) ok = ok && r.second.first == r.second.second;
+        }
         if (ok && slot == 0) {
           const auto want = cpu->SortKeyValue(keys[size_t(i)], values[size_t(i)]);
           ok = want.keys == k && want.values == v;
