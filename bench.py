@@ -127,24 +127,33 @@ def timed_sorts(torch, dist, executor, n, steps, warmup, key_value, device, dist
 
 
 def stage_profile(torch, sorter, n, key_value, device, repeats=5):
-    """Per-kernel durations from the 15-slot timestamp contract (HIP events on the sort's own
-    stream): returns (histogram_ms, mean onesweep launch ms)."""
+    """Per-kernel durations from the 15-slot timestamp contract (HIP events on the sort's own stream): returns
+    (histogram_ms, mean onesweep launch ms).  The stamped sort runs right BEHIND another sort of a different array,
+    like every sort of the timed region does: a kernel is charged for the write-back of what the kernel before it
+    has just written (the histogram takes 30 us after an idle gap and 40-44 us behind a
+    sort), and with the stream busy the host's enqueue latency stays out of the stamps."""
     import vulkan_radix_sort_amd as vrdx
     stream = torch.cuda.current_stream().cuda_stream
     req = sorter.key_value_storage_requirements(n) if key_value else sorter.storage_requirements(n)
     storage = torch.empty(req.size, dtype=torch.uint8, device=device)
     pool = vrdx.QueryPool(15)
     hist, sweep = [], []
-    for r in range(repeats + 1):
-        k, v = reference_stream(77 + r, n)
-        keys = to_device(torch, k, device)
-        values = to_device(torch, v, device) if key_value else None
-        torch.cuda.synchronize()
+
+    def record(keys, values, query_pool):
         if key_value:
             sorter.cmd_sort_key_value(stream, n, keys.data_ptr(), 0, values.data_ptr(), 0, storage.data_ptr(), 0,
-                                      pool, 0)
+                                      query_pool, 0)
         else:
-            sorter.cmd_sort(stream, n, keys.data_ptr(), 0, storage.data_ptr(), 0, pool, 0)
+            sorter.cmd_sort(stream, n, keys.data_ptr(), 0, storage.data_ptr(), 0, query_pool, 0)
+
+    for r in range(repeats + 1):
+        arrays = []
+        for seed in (77 + 2 * r, 78 + 2 * r):
+            k, v = reference_stream(seed, n)
+            arrays.append((to_device(torch, k, device), to_device(torch, v, device) if key_value else None))
+        torch.cuda.synchronize()
+        record(arrays[0][0], arrays[0][1], None)   # the sort in front
+        record(arrays[1][0], arrays[1][1], pool)   # the stamped one
         torch.cuda.synchronize()
         ts = pool.results_ns()
         if r == 0:
@@ -244,14 +253,43 @@ def kernel_source_digest():
     return h.hexdigest()
 
 
+def visible_gpu_count():
+    """GPUs this process could use, WITHOUT touching a GPU runtime (torch.cuda.device_count() may initialise HIP in
+    the parent of the ranks): the KFD topology in sysfs (nodes with SIMDs are GPUs), narrowed by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set.  None when sysfs says nothing; the ranks then check
+    themselves (a world size that differs from --gpus is exit code 2, see main())."""
+    import glob
+    count = 0
+    if not os.path.isdir("/sys/class/kfd"):
+        return 0  # no amdgpu compute driver on this machine at all
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    for path in nodes:
+        try:
+            with open(path) as f:
+                for line in f:
+                    if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                        count += 1
+        except (OSError, ValueError):
+            return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        listed = os.environ.get(var)
+        if listed is not None:
+            count = min(count, len([x for x in listed.split(",") if x.strip() != ""]))
+    return count
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks (torch.distributed.run) as a CHILD
-    process -- this process imports neither torch nor the HIP library, so it never touches a GPU -- and exit
-    with the child's code.  (Never exec from a process that holds a GPU context.)"""
+    process -- this process imports neither torch nor the HIP library (the GPUs are counted in sysfs), so it
+    never touches a GPU -- and exit with the child's code.  (Never exec from a process that holds a GPU context.)"""
     import socket
     import subprocess
-    # (no GPU query here, not even a device count: whatever the launched ranks find is checked by the ranks
-    # themselves -- a world size that differs from --gpus is exit code 2, see main())
+    have = visible_gpu_count()
+    if have is not None and have < args.gpus:
+        print(f"[bench] --gpus {args.gpus} but this node exposes {have} GPU(s)", file=sys.stderr)
+        return 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -277,6 +315,9 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():   # (a rank process: querying the GPU runtime is fine here)
+        print(f"[bench] --gpus {args.gpus} but this node exposes {torch.cuda.device_count()} GPU(s)", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     if distributed:
