@@ -205,8 +205,10 @@ def kernel_name(version, which):
     m = re.search(which + r"=(\d+)x(\d+)(x2)?", version)
     if not m:
         return "onesweep_kernel"
+    if m.group(3):
+        return "onesweep_pair_kernel<%s, %s>" % (m.group(1), m.group(2))   # keys-only, one-atomic ranking
     kv = "true" if which == "key-value" else "false"
-    return "%s<%s, %s, %s, true>" % ("onesweep_pair_kernel" if m.group(3) else "onesweep_kernel", m.group(1), m.group(2), kv)
+    return "onesweep_kernel<%s, %s, %s, true>" % (m.group(1), m.group(2), kv)
 
 
 def latest_pmc_traffic(version):

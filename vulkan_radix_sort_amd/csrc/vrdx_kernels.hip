@@ -1014,6 +1014,9 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
 // B's loads fly while A is scanned and regrouped.  Inside the tile A precedes B (B's digit base is
 // the tile's base + countA), so the result is the same stable permutation.
 //
+// Keys-only sorts with the one-atomic ranking only (the key+value and the ballot forms spilled and were never
+// selected).
+//
 // LDS: staging (THREADS*KPT) | wave counters (WAVES*256) | look-back scratch + scan scratch +
 //      ticket | digit offsets of A and of B (2 x 256).
 template <int THREADS, int KPT>
@@ -1028,7 +1031,7 @@ constexpr int PairMinWavesPerSimd() {
   return waves > 8 ? 8 : (waves < 1 ? 1 : waves);
 }
 
-template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK>
+template <int THREADS, int KPT>
 __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) void onesweep_pair_kernel(OnesweepArgs a) {
   constexpr int WAVES = THREADS / 64;
   constexpr int GROUPS = THREADS / 256;
@@ -1069,8 +1072,6 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
   const uint32_t shift = 8u * a.pass;
   const uint32_t* const keysIn = plan.fromScratch ? a.keysScratch : a.keysCaller;
   uint32_t* const keysOut = plan.fromScratch ? a.keysCaller : a.keysScratch;
-  const uint32_t* const valuesIn = plan.fromScratch ? a.valuesScratch : a.valuesCaller;
-  uint32_t* const valuesOut = plan.fromScratch ? a.valuesCaller : a.valuesScratch;
   if (plan.skip) {  // see onesweep_kernel
     if (a.statusNext != nullptr) {
       if (tid < 256 && blockIdx.x < a.statusRows) a.statusNext[blockIdx.x * VRDX_RADIX + tid] = 0;
@@ -1091,7 +1092,6 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
     if (tile == 0 && tid == 0) *a.ticketNext = 0;
   }
 
-  static_assert(ATOMIC_RANK, "the two-sub-tile kernel exists with the one-atomic ranking only (ConfigIndex)");
   constexpr bool PACKED = true;  // ranks and positions < SUB <= 65536, two to a register
   const uint32_t loadBaseA = tileStart + wave * (KPT * 64) + lane;
   const uint32_t loadBaseB = loadBaseA + SUB;
@@ -1104,12 +1104,6 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
     StoreStriped<KPT>(keysOut, loadBaseA, n, validA == SUB, keyA);
     LoadStriped<KPT>(keysIn, loadBaseB, n, validB == SUB, 0xFFFFFFFFu, keyA);
     StoreStriped<KPT>(keysOut, loadBaseB, n, validB == SUB, keyA);
-    if constexpr (KV) {
-      LoadStriped<KPT>(valuesIn, loadBaseA, n, validA == SUB, 0u, keyA);
-      StoreStriped<KPT>(valuesOut, loadBaseA, n, validA == SUB, keyA);
-      LoadStriped<KPT>(valuesIn, loadBaseB, n, validB == SUB, 0u, keyA);
-      StoreStriped<KPT>(valuesOut, loadBaseB, n, validB == SUB, keyA);
-    }
     return;
   }
   uint32_t rankA[PACKED ? KPT / 2 : KPT];
@@ -1149,8 +1143,8 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
 
   // ---- A: regroup into the staging buffer; from here to the next barrier a wave only touches ITS
   // row of the counters, so it can clear the row and rank B without waiting for the others -------
-  uint32_t packedPosA[KV ? KPT / 2 : 1];
-  RegroupKeys<KPT, SUB, PACKED, KV>(keyA, rankA, shift, myHist, sorted, packedPosA);
+  uint32_t unusedSlots[1];
+  RegroupKeys<KPT, SUB, PACKED, false>(keyA, rankA, shift, myHist, sorted, unusedSlots);
 #pragma unroll
   for (int i = 0; i < 4; ++i) myHist[lane + 64 * i] = 0;
 
@@ -1198,46 +1192,17 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
   VRDX_STAMP(5);
 
   // ---- scatter A ---------------------------------------------------------------------------------
-  uint32_t digits[KV ? KPT / 4 : 1];
+  uint32_t digits[1];
   uint32_t boundaryDigits = 0;
   const uint32_t boundaryQuadA = BoundaryQuad(tid, localA, countA, validA);
   const uint32_t boundaryQuadB = BoundaryQuad(tid, localB, countB, validB);
-  if constexpr (KV) {
-    uint32_t val[KPT];
-    LoadStriped<KPT>(valuesIn, loadBaseA, n, validA == SUB, 0u, val);  // pad: downsweep.slang:85
-    ScatterStagedKeys<THREADS, KPT, true>(sorted, offsetA, keysOut, validA, shift, tid, boundaryQuadA, digits,
-                                          boundaryDigits);
-    LdsBarrier();
-#pragma unroll
-    for (int i = 0; i < KPT; ++i) sorted[(packedPosA[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
-    LdsBarrier();
-    ScatterStagedValues<THREADS, KPT>(sorted, offsetA, valuesOut, validA, tid, boundaryQuadA, digits,
-                                      boundaryDigits);
-  } else {
-    ScatterStagedKeys<THREADS, KPT, false>(sorted, offsetA, keysOut, validA, shift, tid, boundaryQuadA, digits,
-                                           boundaryDigits);
-  }
+  ScatterStagedKeys<THREADS, KPT, false>(sorted, offsetA, keysOut, validA, shift, tid, boundaryQuadA, digits, boundaryDigits);
   LdsBarrier();  // the staging buffer is free again
 
   // ---- B: regroup, scatter -----------------------------------------------------------------------
-  uint32_t packedPosB[KV ? KPT / 2 : 1];
-  RegroupKeys<KPT, SUB, PACKED, KV>(keyB, rankB, shift, myHist, sorted, packedPosB);
+  RegroupKeys<KPT, SUB, PACKED, false>(keyB, rankB, shift, myHist, sorted, unusedSlots);
   LdsBarrier();
-  if constexpr (KV) {
-    uint32_t val[KPT];
-    LoadStriped<KPT>(valuesIn, loadBaseB, n, validB == SUB, 0u, val);
-    ScatterStagedKeys<THREADS, KPT, true>(sorted, offsetB, keysOut, validB, shift, tid, boundaryQuadB, digits,
-                                          boundaryDigits);
-    LdsBarrier();
-#pragma unroll
-    for (int i = 0; i < KPT; ++i) sorted[(packedPosB[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
-    LdsBarrier();
-    ScatterStagedValues<THREADS, KPT>(sorted, offsetB, valuesOut, validB, tid, boundaryQuadB, digits,
-                                      boundaryDigits);
-  } else {
-    ScatterStagedKeys<THREADS, KPT, false>(sorted, offsetB, keysOut, validB, shift, tid, boundaryQuadB, digits,
-                                           boundaryDigits);
-  }
+  ScatterStagedKeys<THREADS, KPT, false>(sorted, offsetB, keysOut, validB, shift, tid, boundaryQuadB, digits, boundaryDigits);
 #ifdef VRDX_TRACE
   VRDX_STAMP(6);
   if (a.trace != nullptr && tid == 0) {
@@ -1416,9 +1381,9 @@ template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK>
 static const void* OnesweepKernel() {
   return reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, KV, ATOMIC_RANK>);
 }
-template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK>
+template <int THREADS, int KPT>
 static const void* PairKernel() {
-  return reinterpret_cast<const void*>(&onesweep_pair_kernel<THREADS, KPT, KV, ATOMIC_RANK>);
+  return reinterpret_cast<const void*>(&onesweep_pair_kernel<THREADS, KPT>);
 }
 
 template <int THREADS, int KPT>
@@ -1460,7 +1425,7 @@ static hipError_t LaunchConfig(hipStream_t stream, uint32_t grid, bool keyValue,
 template <int THREADS, int KPT>
 static hipError_t PreparePairConfig() {
   const int bytes = (int)(PairLdsWords<THREADS, KPT>() * sizeof(uint32_t));
-  return hipFuncSetAttribute(PairKernel<THREADS, KPT, false, true>(), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  return hipFuncSetAttribute(PairKernel<THREADS, KPT>(), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 template <int THREADS, int KPT>
@@ -1468,7 +1433,7 @@ static hipError_t LaunchPairConfig(hipStream_t stream, uint32_t grid, bool keyVa
                                    const OnesweepArgs& args) {
   if (keyValue || !atomicRank) return hipErrorInvalidValue;  // never selected (ConfigIndex)
   const size_t lds = PairLdsWords<THREADS, KPT>() * sizeof(uint32_t);
-  return Launch(PairKernel<THREADS, KPT, false, true>(), grid, THREADS, lds, stream, args);
+  return Launch(PairKernel<THREADS, KPT>(), grid, THREADS, lds, stream, args);
 }
 
 // Every geometry here is selected by ConfigIndex (vrdx_api.cpp) for some size range; nothing else is built.
