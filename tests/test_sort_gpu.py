@@ -309,7 +309,10 @@ def test_timestamp_contract(torch_mod, sorter, oracle):
     dn = sum(ts[4 + 3 * p] - ts[3 + 3 * p] for p in range(4))
     assert up > 0 and dn > 0 and up + sp + dn <= ts[14]
     # the look-back is fused into the pass ("spine" = 0) and slots written back to back share one event
-    assert sp == 0 and ts[14] == ts[13] and all(ts[2 + 3 * p] == ts[1 + 3 * p] for p in range(1, 4))
+    # (2^20 elements record the hybrid plan: its bucket sort sits in pass 1's "upsweep" slot)
+    assert sp == 0 and ts[14] == ts[13] and ts[5] >= ts[4] and all(ts[2 + 3 * p] == ts[1 + 3 * p] for p in range(2, 4))
+    # ... and on these uniform keys the plan applies: launches 1..3 have nothing to do
+    assert ts[10] - ts[9] < 0.6 * (ts[4] - ts[3]) and ts[13] - ts[12] < 0.6 * (ts[4] - ts[3])
     # n == 0 still records all 15 slots
     gpu_sort(torch_mod, sorter, k[:0], v[:0], query_pool=pool)
     assert len(pool.results_ns()) == 15
@@ -438,6 +441,40 @@ def test_device_failure_is_sticky_in_the_sorter_status(torch_mod):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sticky_status_check.py")], cwd=ROOT,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("n", [20_000, 300_000, 1_500_000, (1 << 21)])
+def test_hybrid_plan_and_its_fallback_at_the_bucket_capacity(torch_mod, sorter, oracle, n):
+    """Mid-size sorts record the hybrid plan (scatter by the top byte, then one workgroup per bucket); the DEVICE
+    keeps the four passes when a bucket exceeds the capacity (4096 / 8192 / 16384, twice the mean).  Uniform keys with
+    ONE top byte brought to exactly the capacity (plan applies) and to capacity + 1 (four passes), keys-only and
+    key+value (values = iota: the permutation itself), direct and indirect with a smaller count."""
+    need = 2 * ((n + 255) // 256)
+    cap = 4096 if need <= 4096 else 8192 if need <= 8192 else 16384
+    rng = np.random.default_rng(n)
+    iota = np.arange(n, dtype=np.uint32)
+    for heavy in (cap, cap + 1):
+        k = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+        k[(k >> 24) == 0x5A] ^= np.uint32(0x01000000)          # nobody in bucket 0x5A ...
+        where = rng.choice(n, size=heavy, replace=False)
+        k[where] = (k[where] & np.uint32(0x00FFFFFF)) | np.uint32(0x5A000000)   # ... except exactly `heavy` keys
+        assert int(((k >> 24) == 0x5A).sum()) == heavy
+        ek, ep, _ = oracle.sort(k, iota)
+        gk, _ = gpu_sort(torch_mod, sorter, k)
+        assert np.array_equal(gk, ek), heavy
+        gk, gp = gpu_sort(torch_mod, sorter, k, iota)
+        assert np.array_equal(gk, ek) and np.array_equal(gp, ep), heavy
+        count = n - n // 3
+        ek, ep, _ = oracle.sort(k, iota, count=count)
+        gk, gp = gpu_sort(torch_mod, sorter, k, iota, count=count, indirect=True, max_count=n)
+        assert np.array_equal(gk, ek) and np.array_equal(gp, ep), heavy
+
+
+def test_four_pass_plan_at_mid_sizes_with_the_hybrid_plan_switched_off():
+    """VRDX_HYBRID=0: the native parity battery (255 cases up to 3 M elements) on the four-pass plan alone."""
+    exe = os.path.join(ROOT, "tests", "native", "vrdx_selftest")
+    out = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=1200, env=dict(os.environ, VRDX_HYBRID="0"))
+    assert out.returncode == 0 and ", 0 failures" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
 # one size inside every regime of the size-adaptive tile selection (ConfigIndex in vrdx_api.cpp; f =

@@ -147,6 +147,21 @@ void DumpTrace() {
 }
 #endif
 
+// Mid-size sorts record the hybrid plan (vrdx_kernels.hip, PassPlan) next to the four passes: launch 0 scatters by the
+// keys' highest byte that varies and bucket_sort_kernel finishes every bucket inside one workgroup -- if the DEVICE finds that no bucket
+// exceeds the capacity returned here; otherwise the four passes run as usual and the bucket launch is empty.  The
+// capacity is the smallest of 4096 / 8192 / 16384 that leaves a bucket twice the room of its mean N / 256; 0 = the
+// plan is not recorded (N above 2^21, a forced tile geometry, VRDX_HYBRID=0).
+uint32_t HybridCapacity(uint32_t elementCount) {
+  static const bool enabled = [] {
+    const char* env = std::getenv("VRDX_HYBRID");  // "0": always the four-pass plan (testing / measurements)
+    return env == nullptr || env[0] != '0';
+  }();
+  if (!enabled || elementCount <= vrdx::kSmallSortMaxElements) return 0;
+  const uint32_t need = 2u * ((elementCount + VRDX_RADIX - 1) / VRDX_RADIX);
+  return need <= 4096u ? 4096u : need <= 8192u ? 8192u : need <= 16384u ? 16384u : 0u;
+}
+
 bool SmallSortEnabled() {
   static const bool enabled = [] {
     const char* env = std::getenv("VRDX_SMALL_SORT");  // "0": always take the general path (testing)
@@ -298,6 +313,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   }
 
   const uint32_t tiles = vrdx::RoundUp(elementCount, tileKeys);
+  const uint32_t hybridCap = ForcedConfigIndex() < 0 ? HybridCapacity(elementCount) : 0u;
   // Key+value tiles fetch their values early (right after the ranking: they land during the scan and the
   // regroup) -- on the final kernels that is as fast as or faster than fetching them after the
   // look-back at every size (0-8 %, vrdx_selftest sweep with VRDX_KV_EARLY_VALUES=0|1); the late form
@@ -308,10 +324,25 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   for (uint32_t pass = 0; pass < VRDX_PASSES; ++pass) {
     // "upsweep" of this pass: the fused histogram kernel for pass 0, nothing for the others -- the same
     // point of the stream as the previous pass's "downsweep" stamp
-    if (pass == 0)
+    if (pass == 0) {
       Stamp(pool, query + 2, stream);
-    else
+    } else if (pass == 1 && hybridCap != 0) {
+      // the hybrid plan's second half, between launch 0 and launch 1 (which is empty when the plan applies): its time
+      // is this pass's "upsweep" slot
+      vrdx::BucketSortArgs b;
+      b.keysScratch = keysScratch;
+      b.keysCaller = keys;
+      b.valuesScratch = keyValue ? valuesScratch : nullptr;
+      b.valuesCaller = keyValue ? values : nullptr;
+      b.maxCount = elementCount;
+      b.countPtr = countPtr;
+      b.histogramTable = globalHistogram;
+      b.hybridCap = hybridCap;
+      EnqueueCheck(sorter, "bucket_sort_kernel", vrdx::LaunchBucketSort(stream, keyValue, sorter->atomicRank, b));
+      Stamp(pool, query + 2 + 3 * pass + 0, stream);
+    } else {
       StampSame(pool, query + 2 + 3 * pass + 0, query + 2 + 3 * (pass - 1) + 2);
+    }
     StampSame(pool, query + 2 + 3 * pass + 1, query + 2 + 3 * pass + 0);  // "spine" (fused into the look-back)
 
     vrdx::OnesweepArgs args;
@@ -333,6 +364,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     args.failure = failure;
     args.stickyFailure = sorter->stickyStatus;
     args.pass = pass;
+    args.hybridCap = hybridCap;
     args.spinLimit = vrdx::kSpinLimit;
 #ifdef VRDX_TESTING
     // test build only: VRDX_TEST_SPIN_LIMIT=0 makes the first look-back trip that has to wait give up, which is how
@@ -385,6 +417,7 @@ VkResult vrdxCreateSorter(const VrdxSorterCreateInfo* pCreateInfo, VrdxSorter* p
   hipError_t e = hipSetDevice(ordinal);
   for (int i = 0; i < vrdx::kNumTileConfigs && e == hipSuccess; ++i) e = vrdx::PrepareKernels(i);
   if (e == hipSuccess) e = vrdx::PrepareSmallSort();
+  if (e == hipSuccess) e = vrdx::PrepareBucketSort();
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sorter->stickyStatus), sizeof(uint32_t));
   if (e == hipSuccess) e = hipMemset(sorter->stickyStatus, 0, sizeof(uint32_t));
   if (e == hipSuccess) {

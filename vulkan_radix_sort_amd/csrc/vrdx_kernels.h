@@ -70,7 +70,8 @@ struct OnesweepArgs {
   uint32_t* ticketNext;
   uint32_t* failure;          // word in the caller's storage: this sort's (cleared when the next sort is recorded)
   uint32_t* stickyFailure;    // the sorter's own word: OR over every sort recorded with it (vrdxHipReadSorterStatus)
-  uint32_t pass;              // 0..3: digit = (key >> 8 * pass) & 255
+  uint32_t pass;              // 0..3: digit = (key >> 8 * pass) & 255 (the hybrid plan's launch 0 ranks by byte 3)
+  uint32_t hybridCap;         // 0, or the bucket capacity of the hybrid plan recorded with this sort (PassPlan)
   uint32_t spinLimit;         // look-back trips without progress before the tile gives up (kSpinLimit)
   uint32_t earlyValues;       // KV: fetch the values right after the ranking instead of after the look-back
   unsigned long long* trace;  // phase stamps, 8 per tile; nullptr outside tools/trace.sh builds
@@ -93,6 +94,22 @@ constexpr uint32_t kSmallSortMaxElements = 16384;
 hipError_t PrepareSmallSort();
 hipError_t LaunchSmallSort(hipStream_t stream, bool atomicRank, uint32_t* keys, uint32_t* values, uint32_t maxCount,
                            const uint32_t* countPtr, uint32_t* failure);
+
+// Mid-size sorts, hybrid plan (PassPlan in vrdx_kernels.hip): launch 0 scatters by the keys' highest byte that varies,
+// bucket_sort_kernel sorts each of the 256 buckets by the bytes below it inside one workgroup.  hybridCap = 4096, 8192 or 16384
+// elements per bucket (1024 threads x 4 / 8 / 16); the device decides whether the plan applies.
+struct BucketSortArgs {
+  const uint32_t* keysScratch;
+  uint32_t* keysCaller;
+  const uint32_t* valuesScratch;  // KV only
+  uint32_t* valuesCaller;         // KV only
+  uint32_t maxCount;               // element count (direct) or upper bound (indirect)
+  const uint32_t* countPtr;        // device-side element count (indirect) or nullptr
+  const uint32_t* histogramTable;  // uint[4][256]
+  uint32_t hybridCap;              // elements one workgroup can take (selects the instantiation)
+};
+hipError_t PrepareBucketSort();
+hipError_t LaunchBucketSort(hipStream_t stream, bool keyValue, bool atomicRank, const BucketSortArgs& args);
 
 // Runs the device self-check of the LDS same-address atomic ordering on the current device
 // (synchronous, ~1 ms).  *laneOrdered = true when returning atomics are served in lane order.

@@ -192,7 +192,15 @@ struct PassPlan {
   bool skip;         // nothing to do in this launch
   bool copy;         // identity permutation, but the data has to change buffers
   bool fromScratch;  // this pass reads the storage's scratch arrays and writes the caller's buffers
+  uint32_t digit;    // the byte of the key this launch ranks by (= its pass index, except in the hybrid plan)
 };
+
+// The hybrid plan of mid-size sorts (recorded by the host when hybridCap != 0, chosen HERE, on the device, by every
+// workgroup alike).  Let t be the highest byte of the keys that is not the same in all of them.  If no value of byte t
+// occurs more than hybridCap times, launch 0 scatters by byte t (caller -> scratch), bucket_sort_kernel then sorts
+// each of the 256 buckets by its bytes below t inside one workgroup's LDS (scratch -> caller), and launches 1..3 have
+// nothing to do: two trips through memory instead of up to four, and -- what counts at these sizes -- two dependent
+// kernels instead of four.  Inputs with a bucket that does not fit a workgroup keep the four-pass plan.
 
 // The table loads are issued BEFORE the ticket atomic (LoadPassCounts) and consumed after it
 // (PublishPassVotes): issued after it, wave 0 would wait for the ticket first and then for the loads
@@ -212,28 +220,60 @@ __device__ __forceinline__ PassCounts<THREADS> LoadPassCounts(const uint32_t* hi
   return c;
 }
 
+// flags[0..15]: see above.  flags[16 + g]: "some count of group g exceeds hybridCap" (32 words in all).
 template <int THREADS>
-__device__ __forceinline__ void PublishPassVotes(const PassCounts<THREADS>& c, uint32_t n, int tid, uint32_t* flags) {
+__device__ __forceinline__ void PublishPassVotes(const PassCounts<THREADS>& c, uint32_t n, uint32_t hybridCap, int tid,
+                                                 uint32_t* flags) {
 #pragma unroll
   for (int k = 0; k < (int)(VRDX_PASSES * VRDX_RADIX) / THREADS; ++k) {
+    const int group = (tid + k * THREADS) >> 6;
     const uint64_t any = __ballot(c.v[k] == n);
-    if ((tid & 63) == 0) flags[(tid + k * THREADS) >> 6] = any != 0ull ? 1u : 0u;
+    const uint64_t over = __ballot(c.v[k] > hybridCap);
+    if ((tid & 63) == 0) {
+      flags[group] = any != 0ull ? 1u : 0u;
+      flags[16 + group] = over != 0ull ? 1u : 0u;
+    }
   }
 }
 
-__device__ __forceinline__ PassPlan ReadPassPlan(const uint32_t* flags, uint32_t pass) {
+__device__ __forceinline__ uint32_t TrivialPasses(const uint32_t* flags) {
   uint32_t trivial = 0;
 #pragma unroll
   for (uint32_t q = 0; q < VRDX_PASSES; ++q)
     if ((flags[4 * q] | flags[4 * q + 1] | flags[4 * q + 2] | flags[4 * q + 3]) != 0) trivial |= 1u << q;
+  return trivial;
+}
+
+// The byte the hybrid plan scatters by, or -1 when the plan does not apply (the same answer in every workgroup of
+// every launch of the sort: it follows from the global histogram and the recorded capacity alone).
+__device__ __forceinline__ int HybridByte(const uint32_t* flags, uint32_t hybridCap) {
+  if (hybridCap == 0) return -1;
+  const uint32_t ranked = ~TrivialPasses(flags) & 15u;
+  if (ranked == 0) return -1;  // all keys equal: nothing to sort, the four (empty) passes say so already
+  const int top = 31 - __clz((int)ranked);
+  const bool fits = (flags[16 + 4 * top] | flags[17 + 4 * top] | flags[18 + 4 * top] | flags[19 + 4 * top]) == 0;
+  return fits ? top : -1;
+}
+
+__device__ __forceinline__ PassPlan ReadPassPlan(const uint32_t* flags, uint32_t pass, uint32_t hybridCap) {
+  PassPlan plan;
+  const int hybridByte = HybridByte(flags, hybridCap);
+  if (hybridByte >= 0) {
+    plan.skip = pass != 0;
+    plan.copy = false;
+    plan.fromScratch = false;
+    plan.digit = (uint32_t)hybridByte;
+    return plan;
+  }
+  const uint32_t trivial = TrivialPasses(flags);
   const uint32_t ranked = VRDX_PASSES - (uint32_t)__popc(trivial);
   // odd number of ranking passes: the first trivial pass copies, so that the result ends at the caller
   const uint32_t copier = (ranked & 1u) ? (uint32_t)(__ffs(trivial) - 1) : VRDX_PASSES;
   const uint32_t changes = (~trivial & 15u) | (copier < VRDX_PASSES ? 1u << copier : 0u);
-  PassPlan plan;
   plan.skip = ((changes >> pass) & 1u) == 0;
   plan.copy = !plan.skip && ((trivial >> pass) & 1u) != 0;
   plan.fromScratch = (__popc(changes & ((1u << pass) - 1u)) & 1) != 0;
+  plan.digit = pass;
   return plan;
 }
 
@@ -832,7 +872,7 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   uint32_t* const tileOffset = waveHist + (WAVES - 1) * 256;        // 256: global base - tile-local base (after the regroup)
   uint32_t* const scanScratch = smem;                               // 8   (before the regroup)
   uint32_t* const misc = smem + 8;                                  // [0] ticket (before the regroup)
-  uint32_t* const planFlags = smem + 16;                            // 16 (before the regroup)
+  uint32_t* const planFlags = smem + 16;                            // 32 (before the regroup)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -846,14 +886,14 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   uint32_t key[KPT];
   const PassCounts<THREADS> passCounts = LoadPassCounts<THREADS>(a.histogramTable, tid);
   if (tid == 0) misc[0] = atomicAdd(a.ticketCur, 1u);
-  PublishPassVotes<THREADS>(passCounts, n, tid, planFlags);
+  PublishPassVotes<THREADS>(passCounts, n, a.hybridCap, tid, planFlags);
   for (int i = tid; i < WAVES * 256; i += THREADS) waveHist[i] = 0;
   LdsBarrier();
   VRDX_STAMP(1);
 
   const uint32_t tile = misc[0];
-  const PassPlan plan = ReadPassPlan(planFlags, a.pass);
-  const uint32_t shift = 8u * a.pass;
+  const PassPlan plan = ReadPassPlan(planFlags, a.pass, a.hybridCap);
+  const uint32_t shift = 8u * plan.digit;
   const uint32_t* const keysIn = plan.fromScratch ? a.keysScratch : a.keysCaller;
   uint32_t* const keysOut = plan.fromScratch ? a.keysCaller : a.keysScratch;
   const uint32_t* const valuesIn = plan.fromScratch ? a.valuesScratch : a.valuesCaller;
@@ -930,7 +970,7 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   uint32_t exclusive = 0;
   if (tile == 0) {
     // spine.slang:62-83 equivalent: exclusive scan of this pass's 256 global digit counts.
-    const uint32_t g = tid < 256 ? a.histogramTable[a.pass * VRDX_RADIX + tid] : 0u;
+    const uint32_t g = tid < 256 ? a.histogramTable[plan.digit * VRDX_RADIX + tid] : 0u;
     exclusive = BlockExclusiveScan256(g, scanScratch + 4, tid);
   }
   if (tid < 256) {
@@ -1062,14 +1102,14 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   const PassCounts<THREADS> passCounts = LoadPassCounts<THREADS>(a.histogramTable, tid);
   if (tid == 0) misc[0] = atomicAdd(a.ticketCur, 1u);
-  PublishPassVotes<THREADS>(passCounts, n, tid, misc + 1);
+  PublishPassVotes<THREADS>(passCounts, n, a.hybridCap, tid, misc + 1);
   for (int i = tid; i < WAVES * 256; i += THREADS) waveHist[i] = 0;
   LdsBarrier();
   VRDX_STAMP(1);
 
   const uint32_t tile = misc[0];
-  const PassPlan plan = ReadPassPlan(misc + 1, a.pass);
-  const uint32_t shift = 8u * a.pass;
+  const PassPlan plan = ReadPassPlan(misc + 1, a.pass, a.hybridCap);
+  const uint32_t shift = 8u * plan.digit;
   const uint32_t* const keysIn = plan.fromScratch ? a.keysScratch : a.keysCaller;
   uint32_t* const keysOut = plan.fromScratch ? a.keysCaller : a.keysScratch;
   if (plan.skip) {  // see onesweep_kernel
@@ -1127,7 +1167,7 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
   uint32_t exclusive = 0;
   if (tile == 0) {
     // spine.slang:62-83 equivalent: exclusive scan of this pass's 256 global digit counts.
-    const uint32_t g = tid < 256 ? a.histogramTable[a.pass * VRDX_RADIX + tid] : 0u;
+    const uint32_t g = tid < 256 ? a.histogramTable[plan.digit * VRDX_RADIX + tid] : 0u;
     exclusive = BlockExclusiveScan256(g, scanScratch + 4, tid);
   }
   if (tid < 256) {
@@ -1230,13 +1270,14 @@ constexpr size_t SmallSortLdsWords() {
   return (size_t)THREADS * KPT * (KV ? 2 : 1) + (size_t)(THREADS / 64) * 256 + 16;
 }
 
+// The sort of n <= THREADS * KPT elements by the key bytes [0, bytes) inside one workgroup: in[0..n) -> out[0..n)
+// (in == out: in place).  Used by small_sort_kernel (the whole sort, bytes = 4) and by bucket_sort_kernel (one
+// bucket of the hybrid plan, bytes = 3).
 template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK>
-__global__ __launch_bounds__(THREADS) void small_sort_kernel(uint32_t* keys, uint32_t* values, uint32_t maxCount,
-                                                              const uint32_t* countPtr, uint32_t* failure) {
+__device__ __forceinline__ void SortInWorkgroup(const uint32_t* keysIn, uint32_t* keysOut, const uint32_t* valuesIn,
+                                                uint32_t* valuesOut, uint32_t n, uint32_t bytes, uint32_t* smem) {
   constexpr int WAVES = THREADS / 64;
   constexpr uint32_t TILE = THREADS * KPT;
-  static_assert(THREADS >= 256 && THREADS % 256 == 0, "one thread per digit");
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* const stagedKeys = smem;                              // TILE
   uint32_t* const stagedValues = smem + TILE;                     // TILE (key+value)
   uint32_t* const waveHist = smem + TILE * (KV ? 2 : 1);          // WAVES x 256
@@ -1246,17 +1287,15 @@ __global__ __launch_bounds__(THREADS) void small_sort_kernel(uint32_t* keys, uin
   const int lane = tid & 63;
   const int wave = tid >> 6;
   uint32_t* const myHist = waveHist + wave * 256;
-  const uint32_t n = ElementCount(maxCount, countPtr);
   const uint32_t first = wave * (KPT * 64) + lane;  // element i of this lane: first + 64 * i
-  if (tid == 0) *failure = 0;  // the one word of storage vrdxHipReadStatus looks at: nothing here can spin
 
   uint32_t key[KPT];
   uint32_t val[KV ? KPT : 1];
-  LoadStriped<KPT>(keys, first, n, n >= TILE, 0xFFFFFFFFu, key);  // pad: downsweep.slang:81
-  if constexpr (KV) LoadStriped<KPT>(values, first, n, n >= TILE, 0u, val);  // pad: downsweep.slang:85
+  LoadStriped<KPT>(keysIn, first, n, n >= TILE, 0xFFFFFFFFu, key);  // pad: downsweep.slang:81
+  if constexpr (KV) LoadStriped<KPT>(valuesIn, first, n, n >= TILE, 0u, val);  // pad: downsweep.slang:85
 
 #pragma unroll 1
-  for (uint32_t shift = 0; shift < 32; shift += 8) {
+  for (uint32_t shift = 0; shift < 8 * bytes; shift += 8) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) myHist[lane + 64 * i] = 0;  // my own row: no barrier needed before ranking
     uint32_t rank[KPT];
@@ -1303,10 +1342,57 @@ __global__ __launch_bounds__(THREADS) void small_sort_kernel(uint32_t* keys, uin
   for (int i = 0; i < KPT; ++i) {
     const uint32_t index = first + 64 * i;
     if (index < n) {
-      keys[index] = key[i];
-      if constexpr (KV) values[index] = val[i];
+      keysOut[index] = key[i];
+      if constexpr (KV) valuesOut[index] = val[i];
     }
   }
+}
+
+template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK>
+__global__ __launch_bounds__(THREADS) void small_sort_kernel(uint32_t* keys, uint32_t* values, uint32_t maxCount,
+                                                              const uint32_t* countPtr, uint32_t* failure) {
+  static_assert(THREADS >= 256 && THREADS % 256 == 0, "one thread per digit");
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t n = ElementCount(maxCount, countPtr);
+  if (threadIdx.x == 0) *failure = 0;  // the one word of storage vrdxHipReadStatus looks at: nothing here can spin
+  SortInWorkgroup<THREADS, KPT, KV, ATOMIC_RANK>(keys, keys, values, values, n, VRDX_PASSES, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// bucket_sort_kernel: second half of the hybrid plan of mid-size sorts (see PassPlan)
+// ---------------------------------------------------------------------------------------------
+// Launch 0 has scattered the elements by byte t of the key (PassPlan) into the scratch arrays: bucket b is the range
+// [base[b], base[b] + count[b]) with count = row t of the global histogram and base its exclusive scan.  Workgroup b
+// sorts bucket b by the bytes below t with SortInWorkgroup (stable, so equal keys keep the order launch 0 left them
+// in, which is their input order) and writes it to the same range of the caller's arrays.  Every workgroup first
+// derives, from the same table as the pass kernels, whether the hybrid plan applies at all; otherwise this launch has
+// nothing to do (the four-pass plan is running).
+
+template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK>
+__global__ __launch_bounds__(THREADS) void bucket_sort_kernel(BucketSortArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  uint32_t* const flags = smem + 16;  // 32
+  const int tid = threadIdx.x;
+  // the same votes, from the same table, as in the pass kernels: every launch of the sort reaches the same verdict
+  const uint32_t n = ElementCount(a.maxCount, a.countPtr);
+  const PassCounts<THREADS> passCounts = LoadPassCounts<THREADS>(a.histogramTable, tid);
+  PublishPassVotes<THREADS>(passCounts, n, a.hybridCap, tid, flags);
+  LdsBarrier();
+  const int byte = HybridByte(flags, a.hybridCap);
+  if (byte < 0) return;  // uniform: the four-pass plan is running
+  const uint32_t count = tid < 256 ? a.histogramTable[byte * VRDX_RADIX + tid] : 0u;
+  const uint32_t base = BlockExclusiveScan256(count, smem, tid);
+  if (tid == (int)blockIdx.x) {
+    smem[8] = base;
+    smem[9] = count;
+  }
+  LdsBarrier();
+  const uint32_t myBase = smem[8], myCount = smem[9];
+  LdsBarrier();  // smem is the sort's from here on
+  if (myCount == 0) return;  // uniform
+  SortInWorkgroup<THREADS, KPT, KV, ATOMIC_RANK>(a.keysScratch + myBase, a.keysCaller + myBase,
+                                                 KV ? a.valuesScratch + myBase : nullptr,
+                                                 KV ? a.valuesCaller + myBase : nullptr, myCount, (uint32_t)byte, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1522,6 +1608,54 @@ hipError_t LaunchSmallSort(hipStream_t stream, bool atomicRank, uint32_t* keys, 
                            const uint32_t* countPtr, uint32_t* failure) {
   if (maxCount <= 256u * 16u) return LaunchSmall<256, 16>(stream, atomicRank, keys, values, maxCount, countPtr, failure);
   return LaunchSmall<1024, 16>(stream, atomicRank, keys, values, maxCount, countPtr, failure);
+}
+
+// ---- second half of the hybrid plan ---------------------------------------------------------------
+template <int KPT, bool KV, bool ATOMIC_RANK>
+static const void* BucketKernel() {
+  return reinterpret_cast<const void*>(&bucket_sort_kernel<1024, KPT, KV, ATOMIC_RANK>);
+}
+
+template <int KPT>
+static hipError_t PrepareBucket() {
+  const struct {
+    const void* fn;
+    size_t words;
+  } kernels[4] = {
+      {BucketKernel<KPT, false, false>(), SmallSortLdsWords<1024, KPT, false>()},
+      {BucketKernel<KPT, false, true>(), SmallSortLdsWords<1024, KPT, false>()},
+      {BucketKernel<KPT, true, false>(), SmallSortLdsWords<1024, KPT, true>()},
+      {BucketKernel<KPT, true, true>(), SmallSortLdsWords<1024, KPT, true>()},
+  };
+  for (const auto& k : kernels) {
+    const hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(k.words * 4));
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+template <int KPT>
+static hipError_t LaunchBucket(hipStream_t stream, bool keyValue, bool atomicRank, const BucketSortArgs& args) {
+  const size_t lds = (keyValue ? SmallSortLdsWords<1024, KPT, true>() : SmallSortLdsWords<1024, KPT, false>()) * 4;
+  const void* const kernel = keyValue ? (atomicRank ? BucketKernel<KPT, true, true>() : BucketKernel<KPT, true, false>())
+                                      : (atomicRank ? BucketKernel<KPT, false, true>() : BucketKernel<KPT, false, false>());
+  return Launch(kernel, VRDX_RADIX, 1024, lds, stream, args);
+}
+
+hipError_t PrepareBucketSort() {
+  hipError_t e = PrepareBucket<4>();
+  if (e == hipSuccess) e = PrepareBucket<8>();
+  if (e == hipSuccess) e = PrepareBucket<16>();
+  return e;
+}
+
+hipError_t LaunchBucketSort(hipStream_t stream, bool keyValue, bool atomicRank, const BucketSortArgs& args) {
+  switch (args.hybridCap) {
+    case 1024u * 4u: return LaunchBucket<4>(stream, keyValue, atomicRank, args);
+    case 1024u * 8u: return LaunchBucket<8>(stream, keyValue, atomicRank, args);
+    case 1024u * 16u: return LaunchBucket<16>(stream, keyValue, atomicRank, args);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t LaunchHistogram(hipStream_t stream, uint32_t grid, const uint32_t* keys, uint32_t maxCount,
