@@ -68,19 +68,20 @@ def random_u32(torch, n, seed, device):
     return to_device(torch, reference_stream(seed, n)[0], device)
 
 
-def timed_sorts(torch, dist, executor, n, steps, warmup, key_value, device, distributed):
+def host_streams(n, steps, warmup):
+    """The inputs of one rank, generated ONCE on the host for both the keys-only and the key+value measurement:
+    warm-up | the K timed steps | K more, each bracketed by events.  Seeds 1, 2, ... like the reference's runs
+    (bench/bench.cc:83-84); other ranks continue the sequence."""
+    total = warmup + 2 * steps
+    seed0 = 1 + total * int(os.environ.get("RANK", "0"))
+    return [reference_stream(seed0 + i, n) for i in range(total)]
+
+
+def timed_sorts(torch, dist, executor, streams, n, steps, warmup, key_value, device, distributed):
     """Returns (wall_seconds_for_K_steps_max_over_ranks, per-step gpu ms list of this rank).
     Every sort goes through the batched front end's per-GPU executor (one array per step and rank)."""
-    total = warmup + 2 * steps   # warm-up | the K timed steps | K more, each bracketed by events
-    # seeds 1, 2, ... like the reference's runs (bench/bench.cc:83-84); other ranks continue the sequence
-    seed0 = 1 + total * int(os.environ.get("RANK", "0"))
-    keys, values = [], ([] if key_value else None)
-    for i in range(total):
-        k, v = reference_stream(seed0 + i, n)
-        keys.append(to_device(torch, k, device))
-        if key_value:
-            values.append(to_device(torch, v, device))
-        del k, v
+    keys = [to_device(torch, k, device) for k, _ in streams]
+    values = [to_device(torch, v, device) for _, v in streams] if key_value else None
 
     def one(i):
         executor.enqueue([(keys[i], values[i] if key_value else None)])  # vrdxCmdSort[KeyValue]: never blocks
@@ -336,8 +337,10 @@ def main():
     sorter = executor.sorter
     batch = BatchedSorter(executor=executor)
 
-    wall_keys, steps_keys = timed_sorts(torch, dist, executor, n, args.steps, args.warmup, False, device, distributed)
-    wall_kv, steps_kv = timed_sorts(torch, dist, executor, n, args.steps, args.warmup, True, device, distributed)
+    streams = host_streams(n, args.steps, args.warmup)
+    wall_keys, steps_keys = timed_sorts(torch, dist, executor, streams, n, args.steps, args.warmup, False, device, distributed)
+    wall_kv, steps_kv = timed_sorts(torch, dist, executor, streams, n, args.steps, args.warmup, True, device, distributed)
+    del streams
     hist_ms, sweep_ms = stage_profile(torch, sorter, n, False, device)
     hist_kv_ms, sweep_kv_ms = stage_profile(torch, sorter, n, True, device)
     # end-of-batch record of every rank (the batched variant's only collective; 24 bytes per rank)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Cross-compiles compile-time variants of the library HERE (no GPU needed) into build/variants/<name>/,
-# which travel to the GPU box with the snapshot:   bash tools/build_variants.sh "base: h0:-DVRDX_HIST_EARLY_LOADS=0"
+# which travel to the GPU box with the snapshot:   bash tools/build_variants.sh "base: w16:-DVRDX_LOOKBACK_WINDOW=16"
 # Run them there with tools/run_variants.sh.
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)

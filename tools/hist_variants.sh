@@ -1,6 +1,6 @@
 #!/bin/bash
 # Histogram kernel duration for compile-time variants, run ON the GPU box:
-#   gpurun -- 'bash tools/hist_variants.sh "base: u8:-DVRDX_HIST_UNROLL=8" "25 23"'
+#   gpurun -- 'bash tools/hist_variants.sh "base: c16:-DVRDX_HIST_COPIES_LARGE=16" "25 23"'
 VARIANTS=${1:-"base:"}
 LOGS=${2:-"25"}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)

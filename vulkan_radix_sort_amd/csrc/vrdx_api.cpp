@@ -296,11 +296,11 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   // upsweep of all four passes at once
   {
     // Every workgroup ends with up to 1024 global atomics on the same 1024 words, so few, long-lived
-    // workgroups win for large inputs: one per CU and at least two loop trips each (tools/hist_grid.sh:
+    // workgroups win for large inputs: one per CU and at least two groups of 16384 keys each (tools/hist_grid.sh:
     // 17.4 us with 256 workgroups against 21.1 us with 512 at N = 2^23; equal at 2^25).  Small inputs
     // want the opposite -- the kernel is one memory latency long, so up to 128 workgroups of at least
     // 4096 keys share it: 6.9 instead of 9.7 us at 2^18, 7.9 instead of 9.8 us at 2^20, same at 2^22.
-    uint32_t grid = vrdx::RoundUp(elementCount, 2 * vrdx::kHistKeysPerTrip);
+    uint32_t grid = vrdx::RoundUp(elementCount, 2 * vrdx::kHistGroupKeys);
     const uint32_t wide = std::min<uint32_t>(128u, vrdx::RoundUp(elementCount, 4096u));
     if (grid < wide) grid = wide;
     const uint32_t cap = (uint32_t)sorter->computeUnits * vrdx::kHistWorkgroupsPerCu;

@@ -32,12 +32,9 @@ constexpr uint32_t kHistStreamingLoadsAbove = 1u << 25;  // histogram: keys (4 B
 constexpr uint32_t kStreamingLoadsAbove = 1u << 24;
 constexpr uint32_t kStreamingLoadsUpTo = 3u << 24;
 constexpr uint32_t HistLdsBytes(uint32_t copies) { return 4u * 256u * copies * 4u; }  // [pass][digit][copy]
-#ifndef VRDX_HIST_UNROLL
-#define VRDX_HIST_UNROLL 4
-#endif
-constexpr uint32_t kHistUnroll = VRDX_HIST_UNROLL;  // 16-byte loads in flight per lane
-// keys one histogram workgroup handles per loop trip (kHistThreads lanes x kHistUnroll uint4 x 4 keys)
-constexpr uint32_t kHistKeysPerTrip = kHistThreads * kHistUnroll * 4;
+// keys one histogram workgroup counts per GROUP (kHistThreads lanes x four 16-byte loads x 4 keys); every wave keeps
+// two groups of loads in flight (vrdx_kernels.hip)
+constexpr uint32_t kHistGroupKeys = kHistThreads * 4 * 4;
 
 struct TileConfig {
   int threads;

@@ -44,9 +44,6 @@ namespace vrdx {
 #ifndef VRDX_HIST_NT
 #define VRDX_HIST_NT 1
 #endif
-#ifndef VRDX_HIST_EARLY_LOADS
-#define VRDX_HIST_EARLY_LOADS 1
-#endif
 
 
 // Timing-only phase trace for tools/trace.sh (never defined in the product build): thread 0 of
@@ -328,7 +325,8 @@ __device__ __forceinline__ uint32_t BlockExclusiveScan256(uint32_t v, uint32_t* 
 // The grid-stride order matters as well: at any time the workgroups read ONE contiguous window of the input.  With
 // one contiguous range per workgroup the same loop takes 37 instead of 30 us at N = 2^25
 // (profiles/r03_chain_free_pass0.txt, "flatc").
-constexpr uint32_t kHistGroupVecs = kHistThreads * 4;      // 16-byte vectors per group (4 per lane)
+constexpr uint32_t kHistGroupVecs = kHistGroupKeys / 4;     // 16-byte vectors per group (4 per lane)
+static_assert(kHistGroupVecs == kHistThreads * 4, "four loads per lane and group");
 
 template <bool NT>
 __device__ __forceinline__ void HistFetch(const u32x4* keys4, uint32_t group, uint32_t tid, uint32_t nvec,
