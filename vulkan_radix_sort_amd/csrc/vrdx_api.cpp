@@ -150,16 +150,20 @@ void DumpTrace() {
 // Mid-size sorts record the hybrid plan (vrdx_kernels.hip, PassPlan) next to the four passes: launch 0 scatters by the
 // keys' highest byte that varies and bucket_sort_kernel finishes every bucket inside one workgroup -- if the DEVICE finds that no bucket
 // exceeds the capacity returned here; otherwise the four passes run as usual and the bucket launch is empty.  The
-// capacity is the smallest of 4096 / 8192 / 16384 that leaves a bucket twice the room of its mean N / 256; 0 = the
-// plan is not recorded (N above 2^21, a forced tile geometry, VRDX_HYBRID=0).
-uint32_t HybridCapacity(uint32_t elementCount) {
+// capacity is the smallest of 4096 / 8192 / 16384 (keys-only sorts with the one-atomic ranking: / 32768) that leaves a
+// bucket twice the room of its mean N / 256; 0 = the plan is not recorded (N above 2^21 resp. 2^22, a forced tile
+// geometry, VRDX_HYBRID=0).
+uint32_t HybridCapacity(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount) {
   static const bool enabled = [] {
     const char* env = std::getenv("VRDX_HYBRID");  // "0": always the four-pass plan (testing / measurements)
     return env == nullptr || env[0] != '0';
   }();
   if (!enabled || elementCount <= vrdx::kSmallSortMaxElements) return 0;
   const uint32_t need = 2u * ((elementCount + VRDX_RADIX - 1) / VRDX_RADIX);
-  return need <= 4096u ? 4096u : need <= 8192u ? 8192u : need <= 16384u ? 16384u : 0u;
+  if (need <= 4096u) return 4096u;
+  if (need <= 8192u) return 8192u;
+  if (need <= 16384u) return 16384u;
+  return need <= 32768u && !keyValue && sorter->atomicRank ? 32768u : 0u;
 }
 
 bool SmallSortEnabled() {
@@ -313,7 +317,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   }
 
   const uint32_t tiles = vrdx::RoundUp(elementCount, tileKeys);
-  const uint32_t hybridCap = ForcedConfigIndex() < 0 ? HybridCapacity(elementCount) : 0u;
+  const uint32_t hybridCap = ForcedConfigIndex() < 0 ? HybridCapacity(sorter, keyValue, elementCount) : 0u;
   // Key+value tiles fetch their values early (right after the ranking: they land during the scan and the
   // regroup) -- on the final kernels that is as fast as or faster than fetching them after the
   // look-back at every size (0-8 %, vrdx_selftest sweep with VRDX_KV_EARLY_VALUES=0|1); the late form

@@ -1644,6 +1644,11 @@ hipError_t PrepareBucketSort() {
   hipError_t e = PrepareBucket<4>();
   if (e == hipSuccess) e = PrepareBucket<8>();
   if (e == hipSuccess) e = PrepareBucket<16>();
+  // 32768-element buckets: keys-only (two staging buffers of that size do not fit the LDS) with the one-atomic ranking
+  // (the ballot form would spill 120 bytes per lane)
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(BucketKernel<32, false, true>(), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(SmallSortLdsWords<1024, 32, false>() * 4));
   return e;
 }
 
@@ -1652,6 +1657,9 @@ hipError_t LaunchBucketSort(hipStream_t stream, bool keyValue, bool atomicRank, 
     case 1024u * 4u: return LaunchBucket<4>(stream, keyValue, atomicRank, args);
     case 1024u * 8u: return LaunchBucket<8>(stream, keyValue, atomicRank, args);
     case 1024u * 16u: return LaunchBucket<16>(stream, keyValue, atomicRank, args);
+    case 1024u * 32u:
+      if (keyValue || !atomicRank) return hipErrorInvalidValue;  // never recorded (HybridCapacity)
+      return Launch(BucketKernel<32, false, true>(), VRDX_RADIX, 1024, SmallSortLdsWords<1024, 32, false>() * 4, stream, args);
     default: return hipErrorInvalidValue;
   }
 }
