@@ -100,6 +100,9 @@ int ConfigIndex(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount
   if (keyValue) {
     if (f <= 0.26) return kCfg1024x8;
     if (f <= 0.53) return kCfg1024x16;
+    // just past one round of 32768-element tiles, two workgroups of 16384 per CU fill the second round's gap
+    // (1.2-2.6 % at 1.07 <= f <= 1.32, profiles/r03_sweep_by_geometry.txt)
+    if (f > 1.0 && f <= 1.35) return kCfg1024x16;
     return kCfg1024x32;
   }
   if (f <= 0.125) return kCfg1024x8;
