@@ -207,9 +207,10 @@ def kernel_name(version, which):
     if not m:
         return "onesweep_kernel"
     if m.group(3):
-        return "onesweep_pair_kernel<%s, %s>" % (m.group(1), m.group(2))   # keys-only, one-atomic ranking
+        # keys-only, one-atomic ranking; last argument: even-split tiles (sorts of one round only, not the bench size)
+        return "onesweep_pair_kernel<%s, %s, false>" % (m.group(1), m.group(2))
     kv = "true" if which == "key-value" else "false"
-    return "onesweep_kernel<%s, %s, %s, true>" % (m.group(1), m.group(2), kv)
+    return "onesweep_kernel<%s, %s, %s, true, false>" % (m.group(1), m.group(2), kv)
 
 
 def latest_pmc_traffic(version):

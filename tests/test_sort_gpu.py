@@ -477,6 +477,23 @@ def test_four_pass_plan_at_mid_sizes_with_the_hybrid_plan_switched_off():
     assert out.returncode == 0 and ", 0 failures" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+@pytest.mark.parametrize("n", [256 * 1024 * 20, 256 * 1024 * 20 + 1, 256 * 1024 * 28 - 5, 256 * 2048 * 20, 256 * 2048 * 24 + 1,
+                               256 * 2048 * 32 - 4095])
+def test_even_split_tiles_at_their_slot_boundaries(torch_mod, sorter, oracle, n):
+    """Keys-only sorts of one round of 1024x32 / 1024x32x2 tiles are cut into 256 EQUAL tiles of s slots per wave
+    (EvenSplitSlots in vrdx_api.cpp, s a multiple of 4): sizes that fill s slots exactly, that need one key more
+    (s + 4), and ragged ones, direct and indirect with a smaller count (whole tiles past the count, a ragged tile in
+    the middle of the grid)."""
+    k, _ = oracle.generate(11, n, 32)
+    ek, _, _ = oracle.sort(k)
+    gk, _ = gpu_sort(torch_mod, sorter, k)
+    assert np.array_equal(gk, ek)
+    count = n - n // 3 - 1
+    ek, _, _ = oracle.sort(k, count=count)
+    gk, _ = gpu_sort(torch_mod, sorter, k, count=count, indirect=True, max_count=n)
+    assert np.array_equal(gk, ek)
+
+
 # one size inside every regime of the size-adaptive tile selection (ConfigIndex in vrdx_api.cpp; f =
 # N / (256 CUs * 32768)): 1024x8 | 1024x16 | 1024x32 | two-sub-tile 1024x32x2 | 1024x16 between
 # rounds | ... -- all ragged (odd) sizes

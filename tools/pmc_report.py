@@ -68,9 +68,9 @@ def main():
     for name in fetch:
         if "onesweep" in name:
             rd, wr = fetch[name] * f4, write.get(name, 0.0) * w4
-            # onesweep_kernel<THREADS, KPT, KV, ATOMIC_RANK>: third argument; onesweep_pair_kernel<THREADS, KPT> is keys-only
+            # onesweep_kernel<THREADS, KPT, KV, ATOMIC_RANK, DYN>: third argument; onesweep_pair_kernel<THREADS, KPT, DYN> is keys-only
             targs = [t.strip() for t in name.split("<", 1)[1].split(">", 1)[0].split(",")]
-            kind = "key_value" if len(targs) > 2 and targs[2] == "true" else "keys"
+            kind = "key_value" if "pair" not in name and len(targs) > 2 and targs[2] == "true" else "keys"
         elif "histogram" in name:
             rd, wr = fetch[name] * f16, write.get(name, 0.0) * w4
             kind = "histogram"

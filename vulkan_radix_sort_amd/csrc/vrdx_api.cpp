@@ -106,7 +106,7 @@ int ConfigIndex(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount
     return kCfg1024x32;
   }
   if (f <= 0.125) return kCfg1024x8;
-  if (f <= 0.55) return kCfg1024x16;
+  if (f <= 0.5) return kCfg1024x16;   // beyond: even-split 1024x32 tiles (EvenSplitSlots), 7 % faster at f = 0.536
   if (f <= 1.0) return kCfg1024x32;
   // the two-sub-tile kernel holds two sub-tiles' keys in registers: only with the one-atomic ranking
   const int pair = sorter->atomicRank ? kCfg1024x32x2 : kCfg1024x32;
@@ -222,6 +222,27 @@ void StampSame(VrdxHipQueryPool* pool, uint32_t slot, uint32_t same) {
   pool->source[slot] = pool->source[same];
 }
 
+// Even-split tiles.  The 1024x32 kernels hold one workgroup per CU, so a sort of T tiles takes ceil(T / CUs) rounds
+// however full the last round is: 257 tiles cost two rounds, and so do 512.  When the sort is no more than
+// kEvenSplitRounds rounds long it is cut into rounds * CUs EQUAL tiles instead (a multiple of four 64-key slots per
+// wave), which the kernels' even-split forms (OnesweepArgs::slots) walk with loops of that length.  Returns the slots
+// per wave, or 0 for tiles of the kernel's full capacity.  VRDX_EVEN_SPLIT=0 turns it off (measurements).
+constexpr uint32_t kEvenSplitRounds = 1;
+uint32_t EvenSplitSlots(const VrdxSorter_T* sorter, int configIndex, bool keyValue, uint32_t elementCount) {
+  static const int knob = TuningKnob("VRDX_EVEN_SPLIT");        // 0: off; r > 0: up to r rounds
+  if (knob == 0 || keyValue || (configIndex != kCfg1024x32 && configIndex != kCfg1024x32x2)) return 0;
+  const uint32_t maxRounds = knob > 0 ? (uint32_t)knob : kEvenSplitRounds;
+  const vrdx::TileConfig& c = vrdx::kTileConfigs[configIndex];
+  const uint32_t cus = (uint32_t)sorter->computeUnits;
+  const uint32_t rounds = vrdx::RoundUp(vrdx::RoundUp(elementCount, c.tileKeys()), cus);
+  if (rounds == 0 || rounds > maxRounds) return 0;
+  const uint32_t granule = 4u * (uint32_t)c.threads * (uint32_t)c.subTiles;  // four slots per wave (and sub-tile)
+  const uint32_t perTile = vrdx::RoundUp(elementCount, rounds * cus);
+  uint32_t slots = 4u * vrdx::RoundUp(perTile, granule);
+  if (slots < 8u) slots = 8u;  // status rows fit the reference's storage for tiles of 8192 keys and more (vrdx_layout.h)
+  return slots >= (uint32_t)c.keysPerThread ? 0u : slots;
+}
+
 // reference: gpuSort, src/vk_radix_sort.h.in:344-507
 void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t elementCount,
                 VkBuffer indirectBuffer, VkDeviceSize indirectOffset, VkBuffer keysBuffer,
@@ -248,7 +269,9 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   } deviceScope(sorter->device);
 
   const int configIndex = ConfigIndex(sorter, keyValue, elementCount);
-  const uint32_t tileKeys = vrdx::kTileConfigs[configIndex].tileKeys();
+  const uint32_t evenSlots = EvenSplitSlots(sorter, configIndex, keyValue, elementCount);
+  const uint32_t tileKeys = evenSlots != 0 ? evenSlots * 1024u * (uint32_t)vrdx::kTileConfigs[configIndex].subTiles
+                                           : vrdx::kTileConfigs[configIndex].tileKeys();
   const vrdx::StorageLayout layout =
       vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, tileKeys);
   uint8_t* const storage = BufferAddress(storageBuffer, storageOffset);
@@ -380,6 +403,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     if (testSpinLimit >= 0) args.spinLimit = (uint32_t)testSpinLimit;
 #endif
     args.earlyValues = earlyValues ? 1u : 0u;
+    args.slots = evenSlots;
     args.trace = nullptr;
 #ifdef VRDX_TRACE
     args.trace = TraceBuffer(pass, tiles);
@@ -601,7 +625,7 @@ uint32_t vrdxHipReadSorterStatus(VrdxSorter sorter, VkCommandBuffer commandBuffe
 }
 
 const char* vrdxHipVersionString(void) {
-  static char text[128];
+  static char text[160];
   VrdxSorter_T nominal;  // an MI355X: 256 CUs, lane-ordered LDS atomics
   nominal.computeUnits = 256;
   nominal.atomicRank = true;

@@ -71,6 +71,7 @@ struct OnesweepArgs {
   uint32_t hybridCap;         // 0, or the bucket capacity of the hybrid plan recorded with this sort (PassPlan)
   uint32_t spinLimit;         // look-back trips without progress before the tile gives up (kSpinLimit)
   uint32_t earlyValues;       // KV: fetch the values right after the ranking instead of after the look-back
+  uint32_t slots;             // 0, or even-split tiles: slots of 64 keys per wave (and sub-tile), a multiple of 4 (PlanTiles)
   unsigned long long* trace;  // phase stamps, 8 per tile; nullptr outside tools/trace.sh builds
 };
 

@@ -116,9 +116,12 @@ __device__ __forceinline__ void LdsBarrier() {
 // compiler use ONE offset register plus immediates for all the loads (SGPR base + VGPR offset +
 // imm) instead of a 64-bit address pair per load -- 60 registers that the two-sub-tile kernel
 // does not have.
-template <int KPT, bool NT = false>
+// DYN (even-split tiles, PlanTiles in vrdx_api.cpp): only the first `slots` (a multiple of 4, wave-uniform) of the
+// KPT slots exist; the loops over the slots leave at the first chunk of four that does not, and nothing later reads
+// a slot that was never loaded.
+template <int KPT, bool NT = false, bool DYN = false>
 __device__ __forceinline__ void LoadStriped(const uint32_t* base, uint32_t first, uint32_t n, bool full,
-                                            uint32_t pad, uint32_t (&out)[KPT]) {
+                                            uint32_t pad, uint32_t (&out)[KPT], uint32_t slots = KPT) {
   const char* const bytes = reinterpret_cast<const char*>(base);
   const uint32_t offset = first * 4u;
   // NT: the loads carry the non-temporal bit (StreamingLoads below).  Compile-time on purpose: given both
@@ -129,10 +132,16 @@ __device__ __forceinline__ void LoadStriped(const uint32_t* base, uint32_t first
   };
   if (full) {
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) out[i] = word(i);
+    for (int i = 0; i < KPT; ++i) {
+      if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
+      out[i] = word(i);
+    }
   } else {
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) out[i] = first + i * 64 < n ? word(i) : pad;
+    for (int i = 0; i < KPT; ++i) {
+      if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
+      out[i] = first + i * 64 < n ? word(i) : pad;
+    }
   }
 }
 
@@ -151,28 +160,30 @@ __device__ __forceinline__ bool StreamingLoads(bool keyValue, uint32_t n) {
 // LoadStriped with the kind of load chosen at run time (uniform).  The empty asm statements keep the
 // two arms distinguishable: identical loads at the head or the tail of both would be merged into one
 // plain load.
-template <int KPT>
+template <int KPT, bool DYN = false>
 __device__ __forceinline__ void LoadTile(const uint32_t* base, uint32_t first, uint32_t n, bool full, uint32_t pad,
-                                         uint32_t (&out)[KPT], bool streaming) {
+                                         uint32_t (&out)[KPT], bool streaming, uint32_t slots = KPT) {
   if (streaming) {
     asm volatile("; non-temporal tile loads" ::: "memory");
-    LoadStriped<KPT, true>(base, first, n, full, pad, out);
+    LoadStriped<KPT, true, DYN>(base, first, n, full, pad, out, slots);
     asm volatile("" ::: "memory");
   } else {
-    LoadStriped<KPT, false>(base, first, n, full, pad, out);
+    LoadStriped<KPT, false, DYN>(base, first, n, full, pad, out, slots);
   }
 }
 
 // Wave-striped store, the inverse of LoadStriped: base[first + 64 * i] = in[i] where the index is < n.
-template <int KPT>
+template <int KPT, bool DYN = false>
 __device__ __forceinline__ void StoreStriped(uint32_t* base, uint32_t first, uint32_t n, bool full,
-                                             const uint32_t (&in)[KPT]) {
+                                             const uint32_t (&in)[KPT], uint32_t slots = KPT) {
   char* const bytes = reinterpret_cast<char*>(base);
   const uint32_t offset = first * 4u;
 #pragma unroll
-  for (int i = 0; i < KPT; ++i)
+  for (int i = 0; i < KPT; ++i) {
+    if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
     if (full || first + i * 64 < n)
       *reinterpret_cast<uint32_t*>(bytes + ((uint64_t)offset + (uint64_t)(i * 256))) = in[i];
+  }
 }
 
 // Trivial passes.  If ONE digit of a pass holds every key (16- or 24-bit keys, constant bytes,
@@ -563,13 +574,14 @@ __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t ti
 // Counters are wave-private and LDS serves one wave's operations in program order, so the add of
 // slot i is visible to slot i + 1 without any barrier.
 // PACKED: ranks (< 64 * KPT <= 65536) are written two to a register, out[i / 2] bits 16*(i % 2).
-template <int KPT, bool PACKED = false>
+template <int KPT, bool PACKED = false, bool DYN = false>
 __device__ __forceinline__ void RankBallot(const uint32_t (&key)[KPT], uint32_t shift, uint32_t* myHist,
-                                           int lane, uint32_t (&out)[PACKED ? KPT / 2 : KPT]) {
+                                           int lane, uint32_t (&out)[PACKED ? KPT / 2 : KPT], uint32_t slots = KPT) {
   static_assert(!PACKED || KPT % 2 == 0, "whole pairs");
   uint32_t even = 0;
 #pragma unroll
   for (int i = 0; i < KPT; ++i) {
+    if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
     const uint32_t d = (key[i] >> shift) & 0xFFu;
     const uint64_t same = MatchDigit(d);
     const uint32_t below = LanesBelow(same);
@@ -591,12 +603,13 @@ __device__ __forceinline__ void RankBallot(const uint32_t (&key)[KPT], uint32_t 
 }
 
 // PACKED: ranks (< 64 * KPT <= 65536) are written two to a register, out[i / 2] bits 16*(i % 2).
-template <int KPT, bool PACKED>
+template <int KPT, bool PACKED, bool DYN = false>
 __device__ __forceinline__ void RankAtomic(const uint32_t (&key)[KPT], uint32_t shift, uint32_t* myHist,
-                                           int lane, uint32_t (&out)[PACKED ? KPT / 2 : KPT]) {
+                                           int lane, uint32_t (&out)[PACKED ? KPT / 2 : KPT], uint32_t slots = KPT) {
   // eight slots at a time: eight atomics in flight, eight wave-uniform flags live (more would
-  // push the 64-bit flag masks out of the scalar register file)
-  constexpr int CHUNK = (KPT % 8 == 0) ? 8 : 4;
+  // push the 64-bit flag masks out of the scalar register file); four with a run-time slot count
+  // (the ranking chunk makes no measurable difference: 4 / 8 / 16 / 32 within 1 %, round 2)
+  constexpr int CHUNK = (!DYN && KPT % 8 == 0) ? 8 : 4;
   static_assert(KPT % CHUNK == 0 && CHUNK % 2 == 0, "whole chunks of pairs");
   // The wave-uniform test costs two VALU instructions per key -- 5 % of a pass on random keys, where
   // it never fires (measured by compiling it out).  So a wave keeps testing only while the test pays:
@@ -607,6 +620,7 @@ __device__ __forceinline__ void RankAtomic(const uint32_t (&key)[KPT], uint32_t 
   bool watch = true;  // wave-uniform
 #pragma unroll
   for (int base = 0; base < KPT; base += CHUNK) {
+    if (DYN && (uint32_t)base >= slots) break;
     uint32_t r[CHUNK];
     if (watch) {
       bool uniform[CHUNK];
@@ -673,13 +687,14 @@ __device__ __forceinline__ uint32_t StagingSlot(uint32_t p) {
 // array cannot be reordered by the compiler, so a read-store-read-store source order costs a full
 // LDS round trip per key).  PACKED ranks come two to a register; with KEEP the physical slots are
 // returned packed the same way (key+value stages the values through them).
-template <int KPT, uint32_t STAGE, bool PACKED, bool KEEP>
+template <int KPT, uint32_t STAGE, bool PACKED, bool KEEP, bool DYN = false>
 __device__ __forceinline__ void RegroupKeys(const uint32_t (&key)[KPT], const uint32_t (&rank)[PACKED ? KPT / 2 : KPT],
                                             uint32_t shift, const uint32_t* waveBase, uint32_t* sorted,
-                                            uint32_t (&slots)[KEEP ? KPT / 2 : 1]) {
-  constexpr int CHUNK = (KPT % 8 == 0) ? 8 : 4;
+                                            uint32_t (&slots)[KEEP ? KPT / 2 : 1], uint32_t slotCount = KPT) {
+  constexpr int CHUNK = (!DYN && KPT % 8 == 0) ? 8 : 4;
 #pragma unroll
   for (int base = 0; base < KPT; base += CHUNK) {
+    if (DYN && (uint32_t)base >= slotCount) break;
     uint32_t p[CHUNK];
 #pragma unroll
     for (int c = 0; c < CHUNK; ++c) p[c] = waveBase[(key[base + c] >> shift) & 0xFFu];
@@ -765,15 +780,17 @@ constexpr int ScatterBatch() {
   return quads % want == 0 ? want : (quads % 4 == 0 ? 4 : (quads % 2 == 0 ? 2 : 1));
 }
 
-template <int THREADS, int KPT, bool KEEP_DIGITS>
+// DYN: the frame holds `valid` <= THREADS * slots keys; batches of quads beyond them are not read at all.
+template <int THREADS, int KPT, bool KEEP_DIGITS, bool DYN = false>
 __device__ __forceinline__ void ScatterStagedKeys(const uint32_t* sorted, const uint32_t* offset, uint32_t* out,
                                                   uint32_t valid, uint32_t shift, int tid, uint32_t boundaryQuad,
                                                   uint32_t (&digits)[KEEP_DIGITS ? KPT / 4 : 1],
                                                   uint32_t& boundaryDigits) {
   constexpr uint32_t STAGE = THREADS * KPT;
-  constexpr int B = ScatterBatch<KPT, KEEP_DIGITS>();
+  constexpr int B = DYN ? (KPT % 16 == 0 ? 4 : 1) : ScatterBatch<KPT, KEEP_DIGITS>();
 #pragma unroll
   for (int j0 = 0; j0 < KPT / 4; j0 += B) {
+    if (DYN && 4u * (uint32_t)j0 * THREADS >= valid) break;
     u32x4 k4[B];
     uint32_t o[B];
     bool whole[B];
@@ -800,14 +817,15 @@ __device__ __forceinline__ void ScatterStagedKeys(const uint32_t* sorted, const 
   }
 }
 
-template <int THREADS, int KPT>
+template <int THREADS, int KPT, bool DYN = false>
 __device__ __forceinline__ void ScatterStagedValues(const uint32_t* sorted, const uint32_t* offset, uint32_t* out,
                                                     uint32_t valid, int tid, uint32_t boundaryQuad,
                                                     const uint32_t (&digits)[KPT / 4], uint32_t boundaryDigits) {
   constexpr uint32_t STAGE = THREADS * KPT;
-  constexpr int B = ScatterBatch<KPT, false>();
+  constexpr int B = DYN ? (KPT % 16 == 0 ? 4 : 1) : ScatterBatch<KPT, false>();
 #pragma unroll
   for (int j0 = 0; j0 < KPT / 4; j0 += B) {
+    if (DYN && 4u * (uint32_t)j0 * THREADS >= valid) break;
     u32x4 v4[B];
     uint32_t o[B];
 #pragma unroll
@@ -854,7 +872,11 @@ constexpr int MinWavesPerSimd() {
   return waves > 8 ? 8 : (waves < 1 ? 1 : waves);
 }
 
-template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK>
+// DYN: even-split tiles (PlanTiles in vrdx_api.cpp).  A sort of at most one round of tiles is split EVENLY over all
+// the CUs instead of into tiles of the kernel's capacity: every wave takes a.slots (a multiple of 4, < KPT) slots of
+// 64 keys, a tile is a.slots * THREADS keys, and the loops over the slots stop there, so that a tile costs what its
+// keys cost.  The waves still cover the tile in memory order, pads (the sort's last tile only) still sit at its end.
+template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK, bool DYN>
 __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void onesweep_kernel(OnesweepArgs a) {
   constexpr int WAVES = THREADS / 64;
   constexpr uint32_t TILE = THREADS * KPT;
@@ -905,11 +927,14 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
     }
     return;
   }
-  const uint32_t tiles = (n + TILE - 1) / TILE;
+  const uint32_t slots = DYN ? a.slots : (uint32_t)KPT;  // per wave
+  const uint32_t frame = slots * THREADS;                // keys per tile (TILE unless DYN)
+  const uint32_t tiles = (n + frame - 1) / frame;
   if (tile >= tiles) return;  // uniform for the whole workgroup
   const bool lastTile = tile == tiles - 1;
-  const uint32_t tileStart = tile * TILE;
-  const uint32_t valid = (n - tileStart) < TILE ? (n - tileStart) : TILE;
+  const uint32_t tileStart = tile * frame;
+  const uint32_t valid = (n - tileStart) < frame ? (n - tileStart) : frame;
+  const uint32_t tileEnd = tileStart + valid;
 
   // Housekeeping for the NEXT pass (its kernel starts after this one has drained): clear my row
   // of the other status region and the other ticket.
@@ -921,17 +946,17 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   // ---- load: wave-striped, so that (slot, lane) order == memory order inside a wave ----------
   // (the values are fetched once the keys have been staged)
   uint32_t val[KV ? KPT : 1];
-  const uint32_t loadBase = tileStart + wave * (KPT * 64) + lane;
+  const uint32_t loadBase = tileStart + wave * (slots * 64) + lane;
   // Ragged last tile: pad with 0xFFFFFFFF like the reference (downsweep.slang:81).  Pads sit at the
   // highest memory positions of the tile and have digit 255 in every pass, so the stable ranking
   // puts them at tile-local positions >= valid, where nothing is written.
   const bool streaming = KV && StreamingLoads(KV, n);
-  LoadTile<KPT>(keysIn, loadBase, n, valid == TILE, 0xFFFFFFFFu, key, streaming);
+  LoadTile<KPT, DYN>(keysIn, loadBase, tileEnd, valid == frame, 0xFFFFFFFFu, key, streaming, slots);
   if (plan.copy) {  // identity permutation that has to change buffers: copy the tile
-    StoreStriped<KPT>(keysOut, loadBase, n, valid == TILE, key);
+    StoreStriped<KPT, DYN>(keysOut, loadBase, tileEnd, valid == frame, key, slots);
     if constexpr (KV) {
-      LoadTile<KPT>(valuesIn, loadBase, n, valid == TILE, 0u, val, streaming);
-      StoreStriped<KPT>(valuesOut, loadBase, n, valid == TILE, val);
+      LoadTile<KPT, DYN>(valuesIn, loadBase, tileEnd, valid == frame, 0u, val, streaming, slots);
+      StoreStriped<KPT, DYN>(valuesOut, loadBase, tileEnd, valid == frame, val, slots);
     }
     return;
   }
@@ -944,13 +969,13 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   static_assert(!KV || TILE <= 65536, "packed 16-bit positions");
   uint32_t rank[PACKED ? KPT / 2 : KPT];
   if constexpr (ATOMIC_RANK)
-    RankAtomic<KPT, PACKED>(key, shift, waveHist + wave * 256, lane, rank);
+    RankAtomic<KPT, PACKED, DYN>(key, shift, waveHist + wave * 256, lane, rank, slots);
   else
-    RankBallot<KPT, PACKED>(key, shift, waveHist + wave * 256, lane, rank);
+    RankBallot<KPT, PACKED, DYN>(key, shift, waveHist + wave * 256, lane, rank, slots);
   ForgetDerivedValues<KPT>(key);
   // key+value, early form: the values start their trip now and land during the scan and the regroup
   if constexpr (KV) {
-    if (a.earlyValues) LoadTile<KPT>(valuesIn, loadBase, n, valid == TILE, 0u, val, streaming);  // pad: downsweep.slang:85
+    if (a.earlyValues) LoadTile<KPT, DYN>(valuesIn, loadBase, tileEnd, valid == frame, 0u, val, streaming, slots);  // pad: downsweep.slang:85
   }
   LdsBarrier();
   VRDX_STAMP(2);
@@ -985,7 +1010,7 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
 
   // ---- regroup the keys by digit in LDS; key+value keeps the positions for the values ----------
   uint32_t packedPos[KV ? KPT / 2 : 1];
-  RegroupKeys<KPT, TILE, PACKED, KV>(key, rank, shift, waveHist + wave * 256, sorted, packedPos);
+  RegroupKeys<KPT, TILE, PACKED, KV, DYN>(key, rank, shift, waveHist + wave * 256, sorted, packedPos, slots);
   LdsBarrier();  // waveHist is dead from here on: the look-back reuses it as scratch
   VRDX_STAMP(4);
 
@@ -1007,22 +1032,25 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   // of tiles; on the final kernels the early form is as fast or faster everywhere.  Issued right
   // before the look-back the loads queue in front of its agent-scope status reads (6 -> 9 us, measured).
   if constexpr (KV) {
-    if (!a.earlyValues) LoadTile<KPT>(valuesIn, loadBase, n, valid == TILE, 0u, val, streaming);
+    if (!a.earlyValues) LoadTile<KPT, DYN>(valuesIn, loadBase, tileEnd, valid == frame, 0u, val, streaming, slots);
   }
 
   // ---- scatter (ScatterStagedKeys above); key+value replays the permutation for the values ------
   uint32_t digits[KV ? KPT / 4 : 1];  // key+value: first and last digit of every quad, for the value phase
   uint32_t boundaryDigits = 0;
   const uint32_t boundaryQuad = BoundaryQuad(tid, tileExclusive, count, valid);
-  ScatterStagedKeys<THREADS, KPT, KV>(sorted, tileOffset, keysOut, valid, shift, tid, boundaryQuad, digits,
-                                      boundaryDigits);
+  ScatterStagedKeys<THREADS, KPT, KV, DYN>(sorted, tileOffset, keysOut, valid, shift, tid, boundaryQuad, digits,
+                                           boundaryDigits);
   if constexpr (KV) {
     LdsBarrier();  // every key has left the staging buffer
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) sorted[(packedPos[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
+    for (int i = 0; i < KPT; ++i) {
+      if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
+      sorted[(packedPos[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
+    }
     LdsBarrier();
-    ScatterStagedValues<THREADS, KPT>(sorted, tileOffset, valuesOut, valid, tid, boundaryQuad, digits,
-                                      boundaryDigits);
+    ScatterStagedValues<THREADS, KPT, DYN>(sorted, tileOffset, valuesOut, valid, tid, boundaryQuad, digits,
+                                           boundaryDigits);
   }
 #ifdef VRDX_TRACE
   VRDX_STAMP(6);
@@ -1069,12 +1097,11 @@ constexpr int PairMinWavesPerSimd() {
   return waves > 8 ? 8 : (waves < 1 ? 1 : waves);
 }
 
-template <int THREADS, int KPT>
+template <int THREADS, int KPT, bool DYN>  // DYN: even-split tiles, see onesweep_kernel
 __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) void onesweep_pair_kernel(OnesweepArgs a) {
   constexpr int WAVES = THREADS / 64;
   constexpr int GROUPS = THREADS / 256;
   constexpr uint32_t SUB = THREADS * KPT;  // keys per sub-tile == staging buffer words
-  constexpr uint32_t TILE = 2 * SUB;
   static_assert(THREADS >= 256 && THREADS % 256 == 0, "one thread per digit, whole look-back groups");
   static_assert(KPT % 4 == 0, "quads");
   static_assert(SUB <= 65536, "packed 16-bit positions");
@@ -1117,13 +1144,16 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
     }
     return;
   }
-  const uint32_t tiles = (n + TILE - 1) / TILE;
+  const uint32_t slots = DYN ? a.slots : (uint32_t)KPT;  // per wave and sub-tile
+  const uint32_t sub = slots * THREADS;                  // keys per sub-tile (SUB unless DYN)
+  const uint32_t tiles = (n + 2 * sub - 1) / (2 * sub);
   if (tile >= tiles) return;  // uniform for the whole workgroup
   const bool lastTile = tile == tiles - 1;
-  const uint32_t tileStart = tile * TILE;
+  const uint32_t tileStart = tile * (2 * sub);
   const uint32_t left = n - tileStart;
-  const uint32_t validA = left < SUB ? left : SUB;
-  const uint32_t validB = left > SUB ? (left - SUB < SUB ? left - SUB : SUB) : 0u;
+  const uint32_t validA = left < sub ? left : sub;
+  const uint32_t validB = left > sub ? (left - sub < sub ? left - sub : sub) : 0u;
+  const uint32_t endA = tileStart + validA, endB = tileStart + sub + validB;
 
   if (a.statusNext != nullptr) {
     if (tid < 256 && tile < a.statusRows) a.statusNext[tile * VRDX_RADIX + tid] = 0;
@@ -1131,27 +1161,27 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
   }
 
   constexpr bool PACKED = true;  // ranks and positions < SUB <= 65536, two to a register
-  const uint32_t loadBaseA = tileStart + wave * (KPT * 64) + lane;
-  const uint32_t loadBaseB = loadBaseA + SUB;
+  const uint32_t loadBaseA = tileStart + wave * (slots * 64) + lane;
+  const uint32_t loadBaseB = loadBaseA + sub;
   uint32_t* const myHist = waveHist + wave * 256;
 
   // ---- sub-tile A: load, rank ------------------------------------------------------------------
   uint32_t keyA[KPT];
-  LoadStriped<KPT>(keysIn, loadBaseA, n, validA == SUB, 0xFFFFFFFFu, keyA);  // pad: downsweep.slang:81
+  LoadStriped<KPT, false, DYN>(keysIn, loadBaseA, endA, validA == sub, 0xFFFFFFFFu, keyA, slots);  // pad: downsweep.slang:81
   if (plan.copy) {  // identity permutation that has to change buffers: copy both sub-tiles
-    StoreStriped<KPT>(keysOut, loadBaseA, n, validA == SUB, keyA);
-    LoadStriped<KPT>(keysIn, loadBaseB, n, validB == SUB, 0xFFFFFFFFu, keyA);
-    StoreStriped<KPT>(keysOut, loadBaseB, n, validB == SUB, keyA);
+    StoreStriped<KPT, DYN>(keysOut, loadBaseA, endA, validA == sub, keyA, slots);
+    LoadStriped<KPT, false, DYN>(keysIn, loadBaseB, endB, validB == sub, 0xFFFFFFFFu, keyA, slots);
+    StoreStriped<KPT, DYN>(keysOut, loadBaseB, endB, validB == sub, keyA, slots);
     return;
   }
   uint32_t rankA[PACKED ? KPT / 2 : KPT];
-  RankAtomic<KPT, PACKED>(keyA, shift, myHist, lane, rankA);
+  RankAtomic<KPT, PACKED, DYN>(keyA, shift, myHist, lane, rankA, slots);
   ForgetDerivedValues<KPT>(keyA);
 
   // ---- sub-tile B's keys start their trip now ---------------------------------------------------
   __builtin_amdgcn_sched_barrier(0);  // not earlier: A's keys and ranks are live
   uint32_t keyB[KPT];
-  LoadStriped<KPT>(keysIn, loadBaseB, n, validB == SUB, 0xFFFFFFFFu, keyB);
+  LoadStriped<KPT, false, DYN>(keysIn, loadBaseB, endB, validB == sub, 0xFFFFFFFFu, keyB, slots);
   LdsBarrier();
   VRDX_STAMP(2);
 
@@ -1182,12 +1212,12 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
   // ---- A: regroup into the staging buffer; from here to the next barrier a wave only touches ITS
   // row of the counters, so it can clear the row and rank B without waiting for the others -------
   uint32_t unusedSlots[1];
-  RegroupKeys<KPT, SUB, PACKED, false>(keyA, rankA, shift, myHist, sorted, unusedSlots);
+  RegroupKeys<KPT, SUB, PACKED, false, DYN>(keyA, rankA, shift, myHist, sorted, unusedSlots, slots);
 #pragma unroll
   for (int i = 0; i < 4; ++i) myHist[lane + 64 * i] = 0;
 
   uint32_t rankB[PACKED ? KPT / 2 : KPT];
-  RankAtomic<KPT, PACKED>(keyB, shift, myHist, lane, rankB);
+  RankAtomic<KPT, PACKED, DYN>(keyB, shift, myHist, lane, rankB, slots);
   ForgetDerivedValues<KPT>(keyB);
   LdsBarrier();
   VRDX_STAMP(3);
@@ -1234,13 +1264,15 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
   uint32_t boundaryDigits = 0;
   const uint32_t boundaryQuadA = BoundaryQuad(tid, localA, countA, validA);
   const uint32_t boundaryQuadB = BoundaryQuad(tid, localB, countB, validB);
-  ScatterStagedKeys<THREADS, KPT, false>(sorted, offsetA, keysOut, validA, shift, tid, boundaryQuadA, digits, boundaryDigits);
+  ScatterStagedKeys<THREADS, KPT, false, DYN>(sorted, offsetA, keysOut, validA, shift, tid, boundaryQuadA, digits,
+                                              boundaryDigits);
   LdsBarrier();  // the staging buffer is free again
 
   // ---- B: regroup, scatter -----------------------------------------------------------------------
-  RegroupKeys<KPT, SUB, PACKED, false>(keyB, rankB, shift, myHist, sorted, unusedSlots);
+  RegroupKeys<KPT, SUB, PACKED, false, DYN>(keyB, rankB, shift, myHist, sorted, unusedSlots, slots);
   LdsBarrier();
-  ScatterStagedKeys<THREADS, KPT, false>(sorted, offsetB, keysOut, validB, shift, tid, boundaryQuadB, digits, boundaryDigits);
+  ScatterStagedKeys<THREADS, KPT, false, DYN>(sorted, offsetB, keysOut, validB, shift, tid, boundaryQuadB, digits,
+                                              boundaryDigits);
 #ifdef VRDX_TRACE
   VRDX_STAMP(6);
   if (a.trace != nullptr && tid == 0) {
@@ -1461,43 +1493,52 @@ static hipError_t Launch(const void* kernel, uint32_t grid, uint32_t block, size
   return hipLaunchKernel(kernel, dim3(grid), dim3(block), argv, ldsBytes, stream);
 }
 
-template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK>
+template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK, bool DYN = false>
 static const void* OnesweepKernel() {
-  return reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, KV, ATOMIC_RANK>);
+  return reinterpret_cast<const void*>(&onesweep_kernel<THREADS, KPT, KV, ATOMIC_RANK, DYN>);
 }
-template <int THREADS, int KPT>
+template <int THREADS, int KPT, bool DYN = false>
 static const void* PairKernel() {
-  return reinterpret_cast<const void*>(&onesweep_pair_kernel<THREADS, KPT>);
+  return reinterpret_cast<const void*>(&onesweep_pair_kernel<THREADS, KPT, DYN>);
 }
 
-template <int THREADS, int KPT>
+// EVEN: the even-split forms (args.slots != 0) are built for this geometry as well -- keys-only: the key+value
+// kernel with run-time loop bounds needs 12 registers more than the 128 of four waves per SIMD (48 bytes of scratch
+// per lane, 5-10 % slower than full tiles; profiles/r03_even_split.txt), so key+value sorts keep tiles of full capacity.
+template <int THREADS, int KPT, bool EVEN = false>
 static hipError_t PrepareConfig() {
   const int keysBytes = (int)(OnesweepLdsWords<THREADS, KPT, false>() * sizeof(uint32_t));
   const int kvBytes = (int)(OnesweepLdsWords<THREADS, KPT, true>() * sizeof(uint32_t));
   const struct {
     const void* fn;
     int bytes;
-  } kernels[4] = {
+  } kernels[6] = {
       {OnesweepKernel<THREADS, KPT, false, false>(), keysBytes},
       {OnesweepKernel<THREADS, KPT, false, true>(), keysBytes},
       {OnesweepKernel<THREADS, KPT, true, false>(), kvBytes},
       {OnesweepKernel<THREADS, KPT, true, true>(), kvBytes},
+      {OnesweepKernel<THREADS, KPT, false, false, EVEN>(), keysBytes},
+      {OnesweepKernel<THREADS, KPT, false, true, EVEN>(), keysBytes},
   };
-  for (const auto& k : kernels) {
-    const hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, k.bytes);
+  for (int i = 0; i < (EVEN ? 6 : 4); ++i) {
+    const hipError_t e = hipFuncSetAttribute(kernels[i].fn, hipFuncAttributeMaxDynamicSharedMemorySize, kernels[i].bytes);
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
 }
 
-template <int THREADS, int KPT>
+template <int THREADS, int KPT, bool EVEN = false>
 static hipError_t LaunchConfig(hipStream_t stream, uint32_t grid, bool keyValue, bool atomicRank,
                                const OnesweepArgs& args) {
   const size_t lds = (keyValue ? OnesweepLdsWords<THREADS, KPT, true>() : OnesweepLdsWords<THREADS, KPT, false>()) *
                      sizeof(uint32_t);
-  const void* const kernel =
+  const void* kernel =
       keyValue ? (atomicRank ? OnesweepKernel<THREADS, KPT, true, true>() : OnesweepKernel<THREADS, KPT, true, false>())
                : (atomicRank ? OnesweepKernel<THREADS, KPT, false, true>() : OnesweepKernel<THREADS, KPT, false, false>());
+  if (args.slots != 0) {  // even-split tiles
+    if (!EVEN || keyValue || args.slots % 4 != 0 || args.slots > (uint32_t)KPT) return hipErrorInvalidValue;
+    kernel = atomicRank ? OnesweepKernel<THREADS, KPT, false, true, EVEN>() : OnesweepKernel<THREADS, KPT, false, false, EVEN>();
+  }
   return Launch(kernel, grid, THREADS, lds, stream, args);
 }
 
@@ -1509,6 +1550,8 @@ static hipError_t LaunchConfig(hipStream_t stream, uint32_t grid, bool keyValue,
 template <int THREADS, int KPT>
 static hipError_t PreparePairConfig() {
   const int bytes = (int)(PairLdsWords<THREADS, KPT>() * sizeof(uint32_t));
+  const hipError_t e = hipFuncSetAttribute(PairKernel<THREADS, KPT, true>(), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return e;
   return hipFuncSetAttribute(PairKernel<THREADS, KPT>(), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
@@ -1517,6 +1560,10 @@ static hipError_t LaunchPairConfig(hipStream_t stream, uint32_t grid, bool keyVa
                                    const OnesweepArgs& args) {
   if (keyValue || !atomicRank) return hipErrorInvalidValue;  // never selected (ConfigIndex)
   const size_t lds = PairLdsWords<THREADS, KPT>() * sizeof(uint32_t);
+  if (args.slots != 0) {  // even-split tiles
+    if (args.slots % 4 != 0 || args.slots > (uint32_t)KPT) return hipErrorInvalidValue;
+    return Launch(PairKernel<THREADS, KPT, true>(), grid, THREADS, lds, stream, args);
+  }
   return Launch(PairKernel<THREADS, KPT>(), grid, THREADS, lds, stream, args);
 }
 
@@ -1542,7 +1589,7 @@ hipError_t PrepareKernels(int configIndex) {
   switch (configIndex) {
     case 0: return PrepareConfig<1024, 8>();
     case 1: return PrepareConfig<1024, 16>();
-    case 2: return PrepareConfig<1024, 32>();
+    case 2: return PrepareConfig<1024, 32, true>();
     case 3: return PreparePairConfig<1024, 32>();
     default: return hipErrorInvalidValue;
   }
@@ -1678,7 +1725,7 @@ hipError_t LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bo
   switch (configIndex) {
     case 0: return LaunchConfig<1024, 8>(stream, grid, keyValue, atomicRank, args);
     case 1: return LaunchConfig<1024, 16>(stream, grid, keyValue, atomicRank, args);
-    case 2: return LaunchConfig<1024, 32>(stream, grid, keyValue, atomicRank, args);
+    case 2: return LaunchConfig<1024, 32, true>(stream, grid, keyValue, atomicRank, args);
     case 3: return LaunchPairConfig<1024, 32>(stream, grid, keyValue, atomicRank, args);
     default: return hipErrorInvalidValue;
   }
