@@ -150,23 +150,39 @@ void DumpTrace() {
 }
 #endif
 
+// Integer environment knob for the tuning scripts (read once); -1 when unset.
+int TuningKnob(const char* name) {
+  const char* env = std::getenv(name);
+  return env != nullptr ? std::atoi(env) : -1;
+}
+
 // Mid-size sorts record the hybrid plan (vrdx_kernels.hip, PassPlan) next to the four passes: launch 0 scatters by the
 // keys' highest byte that varies and bucket_sort_kernel finishes every bucket inside one workgroup -- if the DEVICE finds that no bucket
 // exceeds the capacity returned here; otherwise the four passes run as usual and the bucket launch is empty.  The
 // capacity is the smallest of 4096 / 8192 / 16384 (keys-only sorts with the one-atomic ranking: / 32768) that leaves a
-// bucket twice the room of its mean N / 256; 0 = the plan is not recorded (N above 2^21 resp. 2^22, a forced tile
-// geometry, VRDX_HYBRID=0).
+// bucket twice the room of its mean N / 256; the largest one is recorded as long as it leaves 10 % (a bucket sort
+// costs what the bucket's elements cost, whatever the capacity; uniform keys spread by a fraction of a percent at
+// these sizes, and a plan that does not apply costs one empty launch, 3 us, where one that does saves 17-25 %):
+// N <= 7.6 M keys-only, 3.8 M key+value.  0 = the plan is not recorded (larger N, a forced tile geometry, VRDX_HYBRID=0).
 uint32_t HybridCapacity(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount) {
   static const bool enabled = [] {
     const char* env = std::getenv("VRDX_HYBRID");  // "0": always the four-pass plan (testing / measurements)
     return env == nullptr || env[0] != '0';
   }();
   if (!enabled || elementCount <= vrdx::kSmallSortMaxElements) return 0;
-  const uint32_t need = 2u * ((elementCount + VRDX_RADIX - 1) / VRDX_RADIX);
+  // percent of the mean bucket a bucket may hold (tools: VRDX_HYBRID_HEADROOM); the LARGEST capacity is tried with
+  // less room than the others: failing costs one empty launch, the plan is worth a fifth to a third of the sort
+  static const int knob = TuningKnob("VRDX_HYBRID_HEADROOM");
+  static const int knobLast = TuningKnob("VRDX_HYBRID_HEADROOM_LAST");
+  const uint64_t mean = (elementCount + VRDX_RADIX - 1) / VRDX_RADIX;
+  const uint32_t need = (uint32_t)(mean * (uint64_t)(knob > 0 ? knob : 200) / 100u);
+  const uint32_t needLast = (uint32_t)(mean * (uint64_t)(knobLast > 0 ? knobLast : 110) / 100u);
+  const uint32_t largest = !keyValue && sorter->atomicRank ? 32768u : 16384u;
   if (need <= 4096u) return 4096u;
   if (need <= 8192u) return 8192u;
   if (need <= 16384u) return 16384u;
-  return need <= 32768u && !keyValue && sorter->atomicRank ? 32768u : 0u;
+  if (need <= largest) return largest;
+  return needLast <= largest ? largest : 0u;
 }
 
 bool SmallSortEnabled() {
@@ -175,12 +191,6 @@ bool SmallSortEnabled() {
     return env == nullptr || env[0] != '0';
   }();
   return enabled;
-}
-
-// Integer environment knob for the tuning scripts (read once); -1 when unset.
-int TuningKnob(const char* name) {
-  const char* env = std::getenv(name);
-  return env != nullptr ? std::atoi(env) : -1;
 }
 
 inline uint8_t* BufferAddress(VkBuffer buffer, VkDeviceSize offset) {

@@ -1303,6 +1303,8 @@ constexpr size_t SmallSortLdsWords() {
 // The sort of n <= THREADS * KPT elements by the key bytes [0, bytes) inside one workgroup: in[0..n) -> out[0..n)
 // (in == out: in place).  Used by small_sort_kernel (the whole sort, bytes = 4) and by bucket_sort_kernel (one
 // bucket of the hybrid plan, bytes = 3).
+// A wave takes only as many slots of 64 elements as n needs (a multiple of four, like the even-split tiles of
+// onesweep_kernel), so a bucket or small sort costs what its elements cost, not what the kernel could hold.
 template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK>
 __device__ __forceinline__ void SortInWorkgroup(const uint32_t* keysIn, uint32_t* keysOut, const uint32_t* valuesIn,
                                                 uint32_t* valuesOut, uint32_t n, uint32_t bytes, uint32_t* smem) {
@@ -1317,12 +1319,18 @@ __device__ __forceinline__ void SortInWorkgroup(const uint32_t* keysIn, uint32_t
   const int lane = tid & 63;
   const int wave = tid >> 6;
   uint32_t* const myHist = waveHist + wave * 256;
-  const uint32_t first = wave * (KPT * 64) + lane;  // element i of this lane: first + 64 * i
+  constexpr bool DYN = KPT >= 8;
+  uint32_t slots = KPT;
+  if constexpr (DYN) {
+    slots = 4u * ((n + 4u * THREADS - 1u) / (4u * THREADS));
+    slots = slots < (uint32_t)KPT ? slots : (uint32_t)KPT;
+  }
+  const uint32_t first = wave * (slots * 64) + lane;  // element i of this lane: first + 64 * i
 
   uint32_t key[KPT];
   uint32_t val[KV ? KPT : 1];
-  LoadStriped<KPT>(keysIn, first, n, n >= TILE, 0xFFFFFFFFu, key);  // pad: downsweep.slang:81
-  if constexpr (KV) LoadStriped<KPT>(valuesIn, first, n, n >= TILE, 0u, val);  // pad: downsweep.slang:85
+  LoadStriped<KPT, false, DYN>(keysIn, first, n, n >= slots * THREADS, 0xFFFFFFFFu, key, slots);  // pad: downsweep.slang:81
+  if constexpr (KV) LoadStriped<KPT, false, DYN>(valuesIn, first, n, n >= slots * THREADS, 0u, val, slots);  // pad: downsweep.slang:85
 
 #pragma unroll 1
   for (uint32_t shift = 0; shift < 8 * bytes; shift += 8) {
@@ -1330,9 +1338,9 @@ __device__ __forceinline__ void SortInWorkgroup(const uint32_t* keysIn, uint32_t
     for (int i = 0; i < 4; ++i) myHist[lane + 64 * i] = 0;  // my own row: no barrier needed before ranking
     uint32_t rank[KPT];
     if constexpr (ATOMIC_RANK)
-      RankAtomic<KPT, false>(key, shift, myHist, lane, rank);
+      RankAtomic<KPT, false, DYN>(key, shift, myHist, lane, rank, slots);
     else
-      RankBallot<KPT>(key, shift, myHist, lane, rank);
+      RankBallot<KPT, false, DYN>(key, shift, myHist, lane, rank, slots);
     LdsBarrier();
 
     uint32_t count = 0;
@@ -1354,6 +1362,7 @@ __device__ __forceinline__ void SortInWorkgroup(const uint32_t* keysIn, uint32_t
 
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
+      if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
       const uint32_t slot = StagingSlot<TILE>(rank[i] + myHist[(key[i] >> shift) & 0xFFu]);
       stagedKeys[slot] = key[i];
       if constexpr (KV) stagedValues[slot] = val[i];
@@ -1361,6 +1370,7 @@ __device__ __forceinline__ void SortInWorkgroup(const uint32_t* keysIn, uint32_t
     LdsBarrier();
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
+      if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
       const uint32_t slot = StagingSlot<TILE>(first + 64 * i);
       key[i] = stagedKeys[slot];
       if constexpr (KV) val[i] = stagedValues[slot];
@@ -1370,6 +1380,7 @@ __device__ __forceinline__ void SortInWorkgroup(const uint32_t* keysIn, uint32_t
 
 #pragma unroll
   for (int i = 0; i < KPT; ++i) {
+    if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
     const uint32_t index = first + 64 * i;
     if (index < n) {
       keysOut[index] = key[i];
