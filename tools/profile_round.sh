@@ -23,3 +23,11 @@ python3 tools/pmc_report.py "$F" "$W" 33554432 $OUT/pmc_traffic.json > $OUT/pmc_
 # 4. native sweep over N (the reference's curve: bench/bench.cc:17-20)
 timeout 600 tests/native/vrdx_selftest bench 15 16 17 18 19 20 21 22 23 24 25 > $OUT/native_sweep.txt 2>&1
 ls -R $OUT | head -40
+# 5. the rest of the round's evidence: adversarial inputs at 2^25, a soak of overlapping sorts, the bench driver's sweep
+#    (hip and rocprim backends), the smoke entry and the GPU test log
+timeout 900 tests/native/vrdx_selftest adversarial 25 > $OUT/adversarial.txt 2>&1
+timeout 300 tests/native/vrdx_selftest soak 120 > $OUT/soak.txt 2>&1
+timeout 900 bench/bench hip -o $OUT/bench_driver_hip.csv > $OUT/bench_driver_hip.log 2>&1
+timeout 900 bench/bench rocprim -o $OUT/bench_driver_rocprim.csv > $OUT/bench_driver_rocprim.log 2>&1
+timeout 600 python3 -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
+if [ "${WITH_TESTS:-0}" = 1 ]; then timeout 1800 python3 -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; fi
