@@ -352,7 +352,7 @@ void Bench(Harness& h, const std::vector<int>& logs) {
   std::printf("%-10s %-6s %10s %10s %12s %10s %8s   [with 15 timestamps] stage ms (hist | scatter x4)\n", "n", "sort",
               "gpu_ms", "wall_ms", "GItems/s", "GB/s", "%8TB/s");
   for (int lg : logs) {
-    const uint32_t n = 1u << lg;
+    const uint32_t n = lg > 64 ? (uint32_t)lg : 1u << lg;  // an argument above 64 is the element count itself
     for (int kv = 0; kv < 2; ++kv) {
       VrdxSorterStorageRequirements req;
       if (kv)
