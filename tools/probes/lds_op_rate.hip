@@ -13,6 +13,10 @@
 //      6  ds_write_b32    random word of a 32768-word buffer (RegroupKeys: staging store)
 //      7  ds_read_b128    consecutive quads (scatter)
 //      8  ds_add_rtn_u32  wave-private row, digits drawn from 4 values (few-distinct)
+//      9  ds_add_rtn_u32  lane 0 only, the SAME digit in every wave's row (sorted input, top pass: RankAtomic's uniform path)
+//     10  ds_add_rtn_u32  all 64 lanes on that one counter
+//     11  ds_add_rtn_u32  lane 0 only, the waves' counters in 16 different banks
+//     12  ds_add_u32      lane 0 only, the same digit in every wave's row, nothing returned
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -53,7 +57,9 @@ __global__ __launch_bounds__(kThreads) void probe(uint32_t* out, unsigned long l
     else if (MODE == 3 || MODE == 4 || MODE == 5) addr[i] = 32768 + wave * 256 + d;
     else if (MODE == 6) addr[i] = (r >> 8) & 32767u;
     else if (MODE == 7) addr[i] = 4u * ((tid + i * kThreads) & 8191u);
-    else addr[i] = 32768 + wave * 256 + ((r >> 8) & 3u) * 37u;
+    else if (MODE == 8) addr[i] = 32768 + wave * 256 + ((r >> 8) & 3u) * 37u;
+    else if (MODE == 11) addr[i] = 32768 + wave * 256 + 5 + wave * 4;
+    else addr[i] = 32768 + wave * 256 + 5;
   }
   uint32_t acc = 0;
   __syncthreads();
@@ -64,8 +70,12 @@ __global__ __launch_bounds__(kThreads) void probe(uint32_t* out, unsigned long l
     for (int i = 0; i < kOps; ++i) {
       if (MODE == 0 || MODE == 1 || MODE == 2 || MODE == 4) {
         __hip_atomic_fetch_add(&lds[addr[i]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      } else if (MODE == 3 || MODE == 8) {
+      } else if (MODE == 3 || MODE == 8 || MODE == 10) {
         acc += __hip_atomic_fetch_add(&lds[addr[i]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else if (MODE == 9 || MODE == 11) {
+        if (lane == 0) acc += __hip_atomic_fetch_add(&lds[addr[i]], 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else if (MODE == 12) {
+        if (lane == 0) __hip_atomic_fetch_add(&lds[addr[i]], 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else if (MODE == 5) {
         acc += __hip_atomic_load(&lds[addr[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else if (MODE == 6) {
@@ -116,5 +126,9 @@ int main() {
   Run<6>("ds_write_b32, random word of 32768");
   Run<7>("ds_read_b128, consecutive quads");
   Run<8>("ds_add_rtn_u32, 4 distinct digits, wave-private row");
+  Run<9>("ds_add_rtn_u32, lane 0 only, one digit in every wave's row");
+  Run<10>("ds_add_rtn_u32, 64 lanes on one counter per wave");
+  Run<11>("ds_add_rtn_u32, lane 0 only, 16 banks");
+  Run<12>("ds_add_u32, lane 0 only, one digit in every wave's row");
   return 0;
 }
