@@ -497,6 +497,27 @@ def test_even_split_tiles_at_their_slot_boundaries(torch_mod, sorter, oracle, n)
     assert np.array_equal(gk, ek)
 
 
+@pytest.mark.parametrize("n", [20_000, 70_001, 3_000_001, 9_000_001, (1 << 24) + 5])
+def test_two_valued_bytes_take_the_ballot_ranking(torch_mod, sorter, oracle, n):
+    """Slots whose 64 digits are ONE or TWO values are ranked with ballots instead of a 32- or 64-way same-address
+    atomic (RankAtomic, vrdx_kernels.hip): small signed integers (bytes 1..3 are 0x00 | 0xFF, mixed lane by lane),
+    dense sorted keys (the top pass sees k and k + 2^24 side by side) and a byte that alternates between two values
+    with a run of a third one in between (slots of three digits fall back to the atomic in the middle of a chunk).
+    Keys-only and key+value (values = iota: the permutation itself), in every size regime incl. the hybrid plan."""
+    rng = np.random.default_rng(n)
+    iota = np.arange(n, dtype=np.uint32)
+    small_signed = rng.integers(-1000, 1000, size=n, dtype=np.int64).astype(np.int32).view(np.uint32)
+    dense_sorted = (np.arange(n, dtype=np.uint64) // 3).astype(np.uint32)          # every key three times, ascending
+    i = np.arange(n, dtype=np.uint64)
+    mixed = (((i & 1) * 0xFF) << 24) | ((i % 4099 == 0) * np.uint64(0x7F0000)) | (rng.integers(0, 1 << 16, size=n, dtype=np.uint64))
+    for k in (small_signed, dense_sorted, mixed.astype(np.uint32)):
+        ek, ep, _ = oracle.sort(k, iota)
+        gk, _ = gpu_sort(torch_mod, sorter, k)
+        assert np.array_equal(gk, ek)
+        gk, gp = gpu_sort(torch_mod, sorter, k, iota)
+        assert np.array_equal(gk, ek) and np.array_equal(gp, ep)
+
+
 # one size inside every regime of the size-adaptive tile selection (ConfigIndex in vrdx_api.cpp; f =
 # N / (256 CUs * 32768)): 1024x8 | 1024x16 | 1024x32 | two-sub-tile 1024x32x2 | 1024x16 between
 # rounds | ... -- all ragged (odd) sizes

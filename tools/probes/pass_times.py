@@ -6,7 +6,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import vulkan_radix_sort_amd as vrdx
 
-n = 1 << 25
+n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 25)
+half = n.bit_length() - 2   # i >> half: 0 | 1 by halves
 i = torch.arange(n, dtype=torch.int64, device="cuda")
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 rnd = torch.randint(0, 1 << 32, (n,), dtype=torch.int64, device="cuda", generator=g)
@@ -14,9 +15,10 @@ lo_sorted = i & 0xFFFFFF
 lo_random = rnd & 0xFFFFFF
 patterns = {
     "uniform random": rnd,
-    "ascending i  (top byte 0 | 1 by halves)": i,
-    "top byte 0 | 1 by halves, low random": ((i >> 24) << 24) | lo_random,
-    "top byte = i >> 23 (4 values), low random": ((i >> 23) << 24) | lo_random,
+    "ascending, top byte 0 | 1 by halves": ((i >> half) << 24) | (i & 0xFFFFFF),
+    "top byte 0 | 1 by halves, low random": ((i >> half) << 24) | lo_random,
+    "top byte = (i >> 16) & 1 (alternating per 65536), low random": (((i >> 16) & 1) << 24) | lo_random,
+    "top byte = (i >> 16) & 15 (16 values per 65536), low random": (((i >> 16) & 15) << 24) | lo_random,
     "top byte random from {0, 1}, low random": ((rnd >> 31) << 24) | lo_random,
     "top byte random from 4 values, low random": ((rnd >> 30) << 24) | lo_random,
 }

@@ -614,7 +614,7 @@ __device__ __forceinline__ void RankAtomic(const uint32_t (&key)[KPT], uint32_t 
   // The wave-uniform test costs two VALU instructions per key -- 5 % of a pass on random keys, where
   // it never fires (measured by compiling it out).  So a wave keeps testing only while the test pays:
   // the first chunk (512 keys) is always tested, and every later chunk is tested iff the last tested
-  // chunk contained a uniform slot.  Sorted, constant and long-run inputs keep the one-lane path;
+  // chunk contained a uniform (or two-digit) slot.  Sorted, constant and long-run inputs keep the one-lane path;
   // random keys drop the test after the first chunk.  (Untested uniform slots are still ranked
   // correctly, by a 64-way same-address atomic: ~60 LDS cycles instead of 2.)
   bool watch = true;  // wave-uniform
@@ -630,10 +630,34 @@ __device__ __forceinline__ void RankAtomic(const uint32_t (&key)[KPT], uint32_t 
         const int i = base + c;
         const uint32_t d = (key[i] >> shift) & 0xFFu;
         const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
-        uniform[c] = __ballot(d != d0) == 0ull;  // wave-uniform
+        const uint64_t others = __ballot(d != d0);
+        uniform[c] = others == 0ull;  // wave-uniform
         any = any || uniform[c];
         uint32_t old = 0;
-        if (!uniform[c] || lane == 0)
+        bool ranked = false;  // wave-uniform
+        if (!uniform[c] && __popcll(others) <= 48) {
+          // A quarter of the lanes and more share the first lane's digit (never on random digits).  If everybody else is
+          // ONE other digit -- a byte that is 0x00 | 0xFF (small signed integers), the top pass of dense sorted keys
+          // (k and k + 2^24 side by side) -- the slot would serialise 32-way on two counters: 64 LDS cycles instead of 9,
+          // 13.6 instead of 2 us of ranking per tile (profiles/r03_few_digit_passes.txt).  Rank it with ballots: the first
+          // lane of each group adds the group's size, a lane's rank is that counter plus the lanes of its group below it.
+          const int leader1 = __builtin_ctzll(others);
+          const uint64_t m1 = __ballot(d == (uint32_t)__builtin_amdgcn_readlane((int)d, leader1));
+          if ((~others | m1) == ~0ull) {
+            const bool first = d == d0;
+            const uint64_t mine = first ? ~others : m1;
+            const uint32_t below = LanesBelow(mine);
+            if (below == 0)
+              old = __hip_atomic_fetch_add(&myHist[d], (uint32_t)__popcll(mine), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t old0 = __builtin_amdgcn_readfirstlane(old);
+            const uint32_t old1 = (uint32_t)__builtin_amdgcn_readlane((int)old, leader1);
+            old = (first ? old0 : old1) + below;
+            ranked = true;
+            any = true;
+          }
+        }
+        if (!ranked && (!uniform[c] || lane == 0))
           old = __hip_atomic_fetch_add(&myHist[d], uniform[c] ? 64u : 1u, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
         r[c] = old;
