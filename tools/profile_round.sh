@@ -27,7 +27,9 @@ ls -R $OUT | head -40
 #    (hip and rocprim backends), the smoke entry and the GPU test log
 timeout 900 tests/native/vrdx_selftest adversarial 25 > $OUT/adversarial.txt 2>&1
 timeout 300 tests/native/vrdx_selftest soak 120 > $OUT/soak.txt 2>&1
-timeout 900 bench/bench hip --no-verify -o $OUT/bench_driver_hip.csv > $OUT/bench_driver_hip.log 2>&1
-timeout 900 bench/bench rocprim --no-verify -o $OUT/bench_driver_rocprim.csv > $OUT/bench_driver_rocprim.log 2>&1
+if [ "${WITH_DRIVER:-0}" = 1 ]; then  # (ten minutes each: the reference's sweep, 64 sizes x 11 runs x fresh mt19937 data)
+  timeout 900 bench/bench hip --no-verify -o $OUT/bench_driver_hip.csv > $OUT/bench_driver_hip.log 2>&1
+  timeout 900 bench/bench rocprim --no-verify -o $OUT/bench_driver_rocprim.csv > $OUT/bench_driver_rocprim.log 2>&1
+fi
 timeout 600 python3 -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
 if [ "${WITH_TESTS:-0}" = 1 ]; then timeout 1800 python3 -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; fi

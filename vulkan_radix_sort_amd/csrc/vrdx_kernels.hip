@@ -611,20 +611,21 @@ __device__ __forceinline__ void RankAtomic(const uint32_t (&key)[KPT], uint32_t 
   // (the ranking chunk makes no measurable difference: 4 / 8 / 16 / 32 within 1 %, round 2)
   constexpr int CHUNK = (!DYN && KPT % 8 == 0) ? 8 : 4;
   static_assert(KPT % CHUNK == 0 && CHUNK % 2 == 0, "whole chunks of pairs");
-  // The wave-uniform test costs two VALU instructions per key -- 5 % of a pass on random keys, where
-  // it never fires (measured by compiling it out).  So a wave keeps testing only while the test pays:
-  // the first chunk (512 keys) is always tested, and every later chunk is tested iff the last tested
-  // chunk contained a uniform (or two-digit) slot.  Sorted, constant and long-run inputs keep the one-lane path;
-  // random keys drop the test after the first chunk.  (Untested uniform slots are still ranked
-  // correctly, by a 64-way same-address atomic: ~60 LDS cycles instead of 2.)
-  bool watch = true;  // wave-uniform
+  // The wave-uniform test costs two VALU instructions per key -- 5 % of a pass on random keys, where it never fires
+  // (measured by compiling it out).  So a chunk is tested ("watched") only if its FIRST slot looks the part: a quarter
+  // of the lanes or more share the first lane's digit -- one probe of five instructions per chunk, never true on random
+  // digits (round 3; before, the first chunk of every tile was tested in full and later chunks while the test kept
+  // firing: 0.6 us per keys-only pass at 2^25).  Sorted, constant, two-valued and long-run inputs take the watched
+  // path chunk after chunk.  (Uniform slots in an unwatched chunk are still ranked correctly, by a 64-way same-address
+  // atomic: ~60 LDS cycles instead of 2.)
 #pragma unroll
   for (int base = 0; base < KPT; base += CHUNK) {
     if (DYN && (uint32_t)base >= slots) break;
     uint32_t r[CHUNK];
+    const uint32_t probe = (key[base] >> shift) & 0xFFu;
+    const bool watch = __popcll(__ballot(probe != (uint32_t)__builtin_amdgcn_readfirstlane(probe))) <= 48;  // wave-uniform
     if (watch) {
       bool uniform[CHUNK];
-      bool any = false;
 #pragma unroll
       for (int c = 0; c < CHUNK; ++c) {
         const int i = base + c;
@@ -632,7 +633,6 @@ __device__ __forceinline__ void RankAtomic(const uint32_t (&key)[KPT], uint32_t 
         const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
         const uint64_t others = __ballot(d != d0);
         uniform[c] = others == 0ull;  // wave-uniform
-        any = any || uniform[c];
         uint32_t old = 0;
         bool ranked = false;  // wave-uniform
         if (!uniform[c] && __popcll(others) <= 48) {
@@ -654,7 +654,6 @@ __device__ __forceinline__ void RankAtomic(const uint32_t (&key)[KPT], uint32_t 
             const uint32_t old1 = (uint32_t)__builtin_amdgcn_readlane((int)old, leader1);
             old = (first ? old0 : old1) + below;
             ranked = true;
-            any = true;
           }
         }
         if (!ranked && (!uniform[c] || lane == 0))
@@ -665,7 +664,6 @@ __device__ __forceinline__ void RankAtomic(const uint32_t (&key)[KPT], uint32_t 
 #pragma unroll
       for (int c = 0; c < CHUNK; ++c)
         if (uniform[c]) r[c] = __builtin_amdgcn_readfirstlane(r[c]) + lane;
-      watch = any;
     } else {
 #pragma unroll
       for (int c = 0; c < CHUNK; ++c)
