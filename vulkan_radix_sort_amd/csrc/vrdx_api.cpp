@@ -378,6 +378,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
       b.countPtr = countPtr;
       b.histogramTable = globalHistogram;
       b.hybridCap = hybridCap;
+      b.planWord = reinterpret_cast<const uint32_t*>(storage + VRDX_OFF_PLAN);
       EnqueueCheck(sorter, "bucket_sort_kernel", vrdx::LaunchBucketSort(stream, keyValue, sorter->atomicRank, b));
       Stamp(pool, query + 2 + 3 * pass + 0, stream);
     } else {
@@ -405,6 +406,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     args.stickyFailure = sorter->stickyStatus;
     args.pass = pass;
     args.hybridCap = hybridCap;
+    args.planWord = reinterpret_cast<uint32_t*>(storage + VRDX_OFF_PLAN);
     args.spinLimit = vrdx::kSpinLimit;
 #ifdef VRDX_TESTING
     // test build only: VRDX_TEST_SPIN_LIMIT=0 makes the first look-back trip that has to wait give up, which is how

@@ -69,6 +69,7 @@ struct OnesweepArgs {
   uint32_t* stickyFailure;    // the sorter's own word: OR over every sort recorded with it (vrdxHipReadSorterStatus)
   uint32_t pass;              // 0..3: digit = (key >> 8 * pass) & 255 (the hybrid plan's launch 0 ranks by byte 3)
   uint32_t hybridCap;         // 0, or the bucket capacity of the hybrid plan recorded with this sort (PassPlan)
+  uint32_t* planWord;         // hybridCap != 0: the verdict word in the storage (VRDX_OFF_PLAN), written by launch 0
   uint32_t spinLimit;         // look-back trips without progress before the tile gives up (kSpinLimit)
   uint32_t earlyValues;       // KV: fetch the values right after the ranking instead of after the look-back
   uint32_t slots;             // 0, or even-split tiles: slots of 64 keys per wave (and sub-tile), a multiple of 4 (PlanTiles)
@@ -105,6 +106,7 @@ struct BucketSortArgs {
   const uint32_t* countPtr;        // device-side element count (indirect) or nullptr
   const uint32_t* histogramTable;  // uint[4][256]
   uint32_t hybridCap;              // elements one workgroup can take (selects the instantiation)
+  const uint32_t* planWord;        // the verdict word in the storage (VRDX_OFF_PLAN), written by launch 0
 };
 hipError_t PrepareBucketSort();
 hipError_t LaunchBucketSort(hipStream_t stream, bool keyValue, bool atomicRank, const BucketSortArgs& args);

@@ -924,6 +924,10 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
 #endif
   VRDX_STAMP(0);
 
+  // Launches 1-3 of a sort whose hybrid plan applies have nothing to do, and launch 0 has said so in one word: they
+  // return after one load instead of after the table, the ticket, the votes and a barrier (4 -> 2 us per empty launch).
+  if (a.hybridCap != 0 && a.pass != 0 && *a.planWord == 1u) return;
+
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   uint32_t key[KPT];
   const PassCounts<THREADS> passCounts = LoadPassCounts<THREADS>(a.histogramTable, tid);
@@ -935,6 +939,8 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
 
   const uint32_t tile = misc[0];
   const PassPlan plan = ReadPassPlan(planFlags, a.pass, a.hybridCap);
+  if (a.hybridCap != 0 && a.pass == 0 && tile == 0 && tid == 0)  // the verdict, for the launches behind this one
+    *a.planWord = HybridByte(planFlags, a.hybridCap) >= 0 ? 1u : 2u;
   const uint32_t shift = 8u * plan.digit;
   const uint32_t* const keysIn = plan.fromScratch ? a.keysScratch : a.keysCaller;
   uint32_t* const keysOut = plan.fromScratch ? a.keysCaller : a.keysScratch;
@@ -1436,6 +1442,7 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(BucketSortArgs a) 
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* const flags = smem + 16;  // 32
   const int tid = threadIdx.x;
+  if (*a.planWord == 2u) return;  // launch 0's verdict: the four passes are running
   // the same votes, from the same table, as in the pass kernels: every launch of the sort reaches the same verdict
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   const PassCounts<THREADS> passCounts = LoadPassCounts<THREADS>(a.histogramTable, tid);

@@ -50,6 +50,9 @@
 /* offsets inside the first 16 bytes */
 #define VRDX_OFF_COUNT 0u
 #define VRDX_OFF_FAILURE 12u
+// word 1 of the storage (zeroed with the rest of the prefix before every sort): the hybrid plan's verdict, written by
+// launch 0 -- 1 = the plan applies (launches 1-3 return at once), 2 = the four passes run (the bucket launch returns)
+#define VRDX_OFF_PLAN 4u
 
 #ifdef __cplusplus
 namespace vrdx {
