@@ -69,11 +69,12 @@ struct OnesweepArgs {
   uint32_t* stickyFailure;    // the sorter's own word: OR over every sort recorded with it (vrdxHipReadSorterStatus)
   uint32_t pass;              // 0..3: digit = (key >> 8 * pass) & 255 (the hybrid plan's launch 0 ranks by byte 3)
   uint32_t hybridCap;         // 0, or the bucket capacity of the hybrid plan recorded with this sort (PassPlan)
-  uint32_t* planWord;         // hybridCap != 0: the verdict word in the storage (VRDX_OFF_PLAN), written by launch 0
   uint32_t spinLimit;         // look-back trips without progress before the tile gives up (kSpinLimit)
   uint32_t earlyValues;       // KV: fetch the values right after the ranking instead of after the look-back
   uint32_t slots;             // 0, or even-split tiles: slots of 64 keys per wave (and sub-tile), a multiple of 4 (PlanTiles)
   unsigned long long* trace;  // phase stamps, 8 per tile; nullptr outside tools/trace.sh builds
+  uint32_t* planWord;         // hybridCap != 0: the verdict word in the storage (VRDX_OFF_PLAN), written by launch 0
+                              // (last on purpose: the argument layout of the kernels that never read it stays as it was)
 };
 
 // Raises the dynamic-LDS limit of both instantiations (keys-only, key-value) of one tile config.

@@ -926,7 +926,13 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
 
   // Launches 1-3 of a sort whose hybrid plan applies have nothing to do, and launch 0 has said so in one word: they
   // return after one load instead of after the table, the ticket, the votes and a barrier (4 -> 2 us per empty launch).
-  if (a.hybridCap != 0 && a.pass != 0 && *a.planWord == 1u) return;
+  // (Not compiled into the key+value 1024x32 form: the hybrid plan is never recorded with it on a 256-CU device -- it
+  // ends at 3.8 M pairs, that geometry starts at 4.4 M -- and the two lines cost that kernel two registers and 1.7 %
+  // at 2^25, measured.  On a device where the two do meet, its launches take the long way to the same verdict.)
+  constexpr bool kVerdictWord = !(KV && KPT == 32);
+  if constexpr (kVerdictWord) {
+    if (a.hybridCap != 0 && a.pass != 0 && *a.planWord == 1u) return;
+  }
 
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   uint32_t key[KPT];
@@ -939,8 +945,10 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
 
   const uint32_t tile = misc[0];
   const PassPlan plan = ReadPassPlan(planFlags, a.pass, a.hybridCap);
-  if (a.hybridCap != 0 && a.pass == 0 && tile == 0 && tid == 0)  // the verdict, for the launches behind this one
-    *a.planWord = HybridByte(planFlags, a.hybridCap) >= 0 ? 1u : 2u;
+  if constexpr (kVerdictWord) {
+    if (a.hybridCap != 0 && a.pass == 0 && tile == 0 && tid == 0)  // the verdict, for the launches behind this one
+      *a.planWord = HybridByte(planFlags, a.hybridCap) >= 0 ? 1u : 2u;
+  }
   const uint32_t shift = 8u * plan.digit;
   const uint32_t* const keysIn = plan.fromScratch ? a.keysScratch : a.keysCaller;
   uint32_t* const keysOut = plan.fromScratch ? a.keysCaller : a.keysScratch;
