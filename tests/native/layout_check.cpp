@@ -1,50 +1,93 @@
-// CPU-only check of vrdx_layout.h: for a sweep of element counts and every tile size in use, the
-// device state (histogram table, two status regions, tickets) stays inside the region the
-// reference's storage formula provides, the tickets keep a 128-byte line to themselves, and the
-// totals equal the oracle's restatement of the reference formulas.  Built and run by
+// CPU-only check of vrdx_layout.h: for a sweep of element counts, every tile geometry in use with every tile plan
+// PlanTiles can make of it (full tiles, even split, tail split; several CU counts) and every 16-byte alignment of the
+// storage address, the device state (histogram table, two status regions, ticket line) and the 128-byte aligned
+// scratch arrays stay inside the size the reference's storage formula provides, nothing overlaps, the plan covers
+// every key exactly once, and the totals equal the oracle's restatement of the reference formulas.  Built and run by
 // tests/test_abi.py (no GPU, no HIP).
 #include <cstdint>
 #include <cstdio>
+#include <initializer_list>
 
 #include "../../vulkan_radix_sort_amd/csrc/vrdx_layout.h"
 
 extern "C" uint64_t vrdx_oracle_storage_size(uint32_t n, uint32_t align, int key_value);
 
 int main() {
-  // the kernels' capacities and strides in between (tiles start a multiple of 256 keys >= 8192 apart, PlanTiles)
-  const uint32_t tileSizes[] = {8192, 8448, 10240, 12288, 14336, 16384, 23808, 32768, 35840, 49408, 65536};
+  struct Geometry {
+    uint32_t threads, keysPerThread, subTiles;
+    bool splitForms;
+  };
+  const Geometry geometries[] = {{1024, 8, 1, false}, {1024, 16, 1, false}, {1024, 32, 1, false}, {1024, 32, 1, true},
+                                 {1024, 32, 2, false}, {1024, 32, 2, true}};
+  const uint32_t cuCounts[] = {256, 304, 64, 8};
   uint64_t cases = 0;
   int failures = 0;
-  auto check = [&](uint32_t n) {
-    for (uint32_t t : tileSizes) {
-      const vrdx::StorageLayout l = vrdx::MakeLayout(n, VRDX_STORAGE_ALIGN, t);
-      ++cases;
-      const uint64_t partitions = ((uint64_t)n + VRDX_REF_PARTITION_SIZE - 1) / VRDX_REF_PARTITION_SIZE;
-      const uint64_t areaEnd = l.statusOffset + partitions * 1024;  // end of the reference's partition histograms
-      const uint64_t region1End = l.statusOffset + 2 * l.statusRows * 1024;
-      bool ok = true;
-      ok = ok && l.keysOnlySize == vrdx_oracle_storage_size(n, VRDX_STORAGE_ALIGN, 0);
-      ok = ok && l.keyValueSize == vrdx_oracle_storage_size(n, VRDX_STORAGE_ALIGN, 1);
-      ok = ok && l.histogramOffset == 16 && l.statusOffset == 16 + 4096;
-      ok = ok && l.clearBytes == l.statusOffset + l.statusRows * 1024;
-      if (n > 0) {
-        ok = ok && region1End <= areaEnd;                       // both status regions fit
-        ok = ok && l.ticketOffset >= region1End + 128;          // a line of their own, after the status words
-        ok = ok && l.ticketOffset + 8 + 120 <= areaEnd + 16;    // ... and still inside the area (+ its 16 B slack)
-        ok = ok && l.ticketOffset + 8 <= l.inoutOffset;
-      }
-      ok = ok && l.inoutOffset == 16 + vrdx::HistogramSize(n, VRDX_STORAGE_ALIGN);
-      if (!ok) {
-        if (failures < 10) std::printf("FAIL n=%u tile=%u\n", n, t);
-        ++failures;
+  auto check = [&](uint32_t n, bool allAlignments) {
+    for (const Geometry& g : geometries) {
+      for (uint32_t cus : cuCounts) {
+        if (!g.splitForms && cus != 256) continue;  // the plan does not depend on the CU count then
+        const vrdx::TilePlan plan = vrdx::PlanTiles(n, cus, g.threads, g.keysPerThread, g.subTiles, g.splitForms, true, 100);
+        // the plan covers [0, n) with tiles of a multiple of four slots, none larger than the kernel's capacity
+        bool ok = true;
+        const uint32_t slotKeys = g.threads * g.subTiles;
+        if (plan.slots == 0) {
+          ok = ok && plan.tiles == vrdx::RoundUp(n, slotKeys * g.keysPerThread);
+        } else {
+          ok = ok && g.splitForms && plan.slots % 4 == 0 && plan.tailSlots % 4 == 0 && plan.tailSlots >= 4;
+          ok = ok && plan.slots <= g.keysPerThread && plan.tailSlots <= g.keysPerThread;
+          const uint64_t frameA = (uint64_t)plan.slots * slotKeys, frameB = (uint64_t)plan.tailSlots * slotKeys;
+          if (plan.fullTiles == ~0u) {
+            ok = ok && (uint64_t)plan.tiles * frameA >= n && (uint64_t)(plan.tiles - 1) * frameA < n;
+            ok = ok && plan.tiles <= cus;
+          } else {
+            const uint64_t keysA = (uint64_t)plan.fullTiles * frameA;
+            ok = ok && plan.slots == g.keysPerThread && plan.fullTiles % cus == 0 && keysA < n && plan.tiles > plan.fullTiles;
+            ok = ok && keysA + (uint64_t)(plan.tiles - plan.fullTiles) * frameB >= n;
+            ok = ok && keysA + (uint64_t)(plan.tiles - plan.fullTiles - 1) * frameB < n;
+            ok = ok && plan.tiles - plan.fullTiles <= cus;
+          }
+        }
+        for (uint32_t address = 0; address < 128; address += 16) {
+          if (!allAlignments && address != 0 && address != 32 && address != 112) continue;
+          const vrdx::StorageLayout l = vrdx::MakeLayout(n, VRDX_STORAGE_ALIGN, plan.tiles, 0x7f0000001000ull + address);
+          ++cases;
+          const uint64_t region1End = l.statusOffset + 2 * l.statusRows * 1024;
+          const uint64_t inoutBytes = (uint64_t)n * 4;
+          ok = ok && l.keysOnlySize == vrdx_oracle_storage_size(n, VRDX_STORAGE_ALIGN, 0);
+          ok = ok && l.keyValueSize == vrdx_oracle_storage_size(n, VRDX_STORAGE_ALIGN, 1);
+          ok = ok && l.histogramOffset == 16 && l.statusOffset >= 16 + 4096 && l.statusOffset < 16 + 4096 + 128;
+          ok = ok && l.statusRows == (plan.tiles > 0 ? plan.tiles - 1 : 0);
+          ok = ok && l.clearBytes == l.statusOffset + l.statusRows * 1024;
+          ok = ok && (address + l.statusOffset) % 128 == 0;            // status rows start on a line
+          ok = ok && l.ticketOffset == region1End;                     // the ticket line: its own, right behind them
+          ok = ok && l.inoutOffset == l.ticketOffset + 128;
+          ok = ok && (address + l.inoutOffset) % 128 == 0 && (address + l.valuesOffset) % 128 == 0;
+          ok = ok && l.valuesOffset >= l.inoutOffset + inoutBytes;     // the scratch arrays do not overlap
+          if (n > 0) {  // (an empty sort touches nothing: vrdx_api.cpp returns before it looks at the layout)
+            ok = ok && l.inoutOffset + inoutBytes <= l.keysOnlySize;   // ... and end inside what the caller allocated
+            ok = ok && l.valuesOffset + inoutBytes <= l.keyValueSize;
+          }
+        }
+        if (!ok) {
+          if (failures < 10)
+            std::printf("FAIL n=%u geometry %ux%ux%u split=%d cus=%u: tiles %u slots %u fullTiles %u tailSlots %u\n", n, g.threads,
+                        g.keysPerThread, g.subTiles, (int)g.splitForms, cus, plan.tiles, plan.slots, plan.fullTiles, plan.tailSlots);
+          ++failures;
+        }
       }
     }
   };
-  for (uint32_t n = 0; n <= 70000; ++n) check(n);
-  for (uint64_t n = 70001; n <= VRDX_MAX_ELEMENTS; n += 1 + n / 977) check((uint32_t)n);
+  for (uint32_t n = 0; n <= 70000; ++n) check(n, n % 97 == 0);
+  for (uint64_t n = 70001; n <= VRDX_MAX_ELEMENTS; n += 1 + n / 977) check((uint32_t)n, false);
   for (uint32_t lg = 10; lg < 30; ++lg)
-    for (int d = -2; d <= 2; ++d) check((1u << lg) + d);
-  check(VRDX_MAX_ELEMENTS);
+    for (int d = -2; d <= 2; ++d) check((1u << lg) + d, true);
+  // the edges of the rounds: multiples of one round of every geometry and CU count, +- a few keys and +- one granule
+  for (uint32_t cus : cuCounts)
+    for (uint32_t capacity : {32768u, 65536u})
+      for (uint32_t rounds = 1; rounds <= 6; ++rounds)
+        for (int d : {-4097, -4096, -1, 0, 1, 2, 4095, 4096, 4097, 8192, 8193})
+          check((uint32_t)((int64_t)rounds * cus * capacity + d), true);
+  check(VRDX_MAX_ELEMENTS, true);
   std::printf("layout: %llu cases, %d failures\n", (unsigned long long)cases, failures);
   return failures != 0;
 }

@@ -45,13 +45,13 @@ int main() {
     for (uint32_t c = 0; c < 256; ++c) total += counts[c];
     if (total != n) ++failures;
     for (uint32_t tile : {8192u, 16384u, 32768u, 65536u}) {
-      const vrdx::StorageLayout l = vrdx::MakeLayout(n, VRDX_STORAGE_ALIGN, tile);
+      const vrdx::StorageLayout l = vrdx::MakeLayout(n, VRDX_STORAGE_ALIGN, vrdx::RoundUp(n, tile), 0x1000u + 16u * (n % 8));
       if (l.keysOnlySize != vrdx_oracle_storage_size(n, VRDX_STORAGE_ALIGN, 0) ||
           l.keyValueSize != vrdx_oracle_storage_size(n, VRDX_STORAGE_ALIGN, 1))
         ++failures;
     }
   }
-  const vrdx::StorageLayout top = vrdx::MakeLayout(VRDX_MAX_ELEMENTS, VRDX_STORAGE_ALIGN, 8192);
+  const vrdx::StorageLayout top = vrdx::MakeLayout(VRDX_MAX_ELEMENTS, VRDX_STORAGE_ALIGN, vrdx::RoundUp(VRDX_MAX_ELEMENTS, 8192));
   if (top.keyValueSize != vrdx_oracle_storage_size(VRDX_MAX_ELEMENTS, VRDX_STORAGE_ALIGN, 1)) ++failures;
   std::printf("sanitized host check: %d failures\n", failures);
   return failures != 0;

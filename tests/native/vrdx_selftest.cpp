@@ -39,6 +39,17 @@ uint64_t vrdx_oracle_storage_size(uint32_t maxElementCount, uint32_t align, int 
 
 namespace {
 
+// VRDX_SELFTEST_STORAGE_OFFSET=<bytes>: the timing modes (bench, sweep, adversarial) hand the storage over at this
+// offset into its allocation (a multiple of 16, like minStorageBufferOffsetAlignment) -- how the alignment of the
+// storage's scratch arrays was measured (profiles/r04_kv_pass_parity.txt).
+VkDeviceSize StorageOffset() {
+  static const VkDeviceSize offset = [] {
+    const char* env = std::getenv("VRDX_SELFTEST_STORAGE_OFFSET");
+    return env != nullptr ? (VkDeviceSize)std::strtoull(env, nullptr, 10) : (VkDeviceSize)0;
+  }();
+  return offset;
+}
+
 constexpr uint32_t kGuard = 64;          // untouched-tail guard elements
 constexpr uint32_t kGuardWord = 0xDEADBEEFu;
 
@@ -260,6 +271,12 @@ int Parity(Harness& h, bool quick) {
   if (!quick) {
     sizes.push_back(5000011);
     sizes.push_back(1u << 24);
+    // tail-split plans (PlanTiles): whole rounds of full tiles, then one round of small equal tiles -- a little and a
+    // lot past one and two rounds of 256 x 32768 (the indirect cases plan for a larger bound than they sort)
+    sizes.push_back((1u << 23) + 4097);
+    sizes.push_back((1u << 23) + (1u << 21) + 77);
+    sizes.push_back((1u << 24) + 70001);
+    sizes.push_back(3u * (1u << 23) + 200003);
   }
   for (uint32_t n : sizes) {
     for (int seed : {1, 42}) {
@@ -360,7 +377,7 @@ void Bench(Harness& h, const std::vector<int>& logs) {
       else
         vrdxGetSorterStorageRequirements(h.sorter, n, &req);
       const uint32_t inout = Align16(n * 4u);
-      h.reserve((size_t)2 * inout + 16, (size_t)req.size);
+      h.reserve((size_t)2 * inout + 16, (size_t)req.size + StorageOffset());
       std::vector<uint64_t> gpu, wall, stage[5];
       for (int runIdx = 0; runIdx < 11; ++runIdx) {  // 1 warm-up + 10 timed, fresh data each run
         std::vector<uint32_t> v;
@@ -371,9 +388,9 @@ void Bench(Harness& h, const std::vector<int>& logs) {
         const auto t0 = std::chrono::steady_clock::now();
         if (kv)
           vrdxCmdSortKeyValue((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dKeys, inout,
-                              (VkBuffer)h.dStorage, 0, h.pool, 0);
+                              (VkBuffer)h.dStorage, StorageOffset(), h.pool, 0);
         else
-          vrdxCmdSort((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dStorage, 0, h.pool, 0);
+          vrdxCmdSort((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dStorage, StorageOffset(), h.pool, 0);
         HIP_OK(hipStreamSynchronize(h.stream));
         const auto t1 = std::chrono::steady_clock::now();
         uint64_t ts[15];
@@ -399,9 +416,9 @@ void Bench(Harness& h, const std::vector<int>& logs) {
           HIP_OK(hipEventRecord(e0, h.stream));
           if (kv)
             vrdxCmdSortKeyValue((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dKeys, inout,
-                                (VkBuffer)h.dStorage, 0, VK_NULL_HANDLE, 0);
+                                (VkBuffer)h.dStorage, StorageOffset(), VK_NULL_HANDLE, 0);
           else
-            vrdxCmdSort((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dStorage, 0,
+            vrdxCmdSort((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dStorage, StorageOffset(),
                         VK_NULL_HANDLE, 0);
           HIP_OK(hipEventRecord(e1, h.stream));
           HIP_OK(hipStreamSynchronize(h.stream));
@@ -436,7 +453,7 @@ void Sweep(Harness& h, double lo, double hi, int points, bool kv) {
   VrdxSorterStorageRequirements req;
   vrdxGetSorterKeyValueStorageRequirements(h.sorter, nMax, &req);
   const uint32_t inoutMax = Align16(nMax * 4u);
-  h.reserve((size_t)2 * inoutMax + 16, (size_t)req.size);
+  h.reserve((size_t)2 * inoutMax + 16, (size_t)req.size + StorageOffset());
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0));
   HIP_OK(hipEventCreate(&e1));
@@ -453,9 +470,9 @@ void Sweep(Harness& h, double lo, double hi, int points, bool kv) {
       HIP_OK(hipEventRecord(e0, h.stream));
       if (kv)
         vrdxCmdSortKeyValue((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dKeys, inout,
-                            (VkBuffer)h.dStorage, 0, VK_NULL_HANDLE, 0);
+                            (VkBuffer)h.dStorage, StorageOffset(), VK_NULL_HANDLE, 0);
       else
-        vrdxCmdSort((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dStorage, 0, VK_NULL_HANDLE, 0);
+        vrdxCmdSort((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dStorage, StorageOffset(), VK_NULL_HANDLE, 0);
       HIP_OK(hipEventRecord(e1, h.stream));
       HIP_OK(hipStreamSynchronize(h.stream));
       float msf = 0;
@@ -471,6 +488,47 @@ void Sweep(Harness& h, double lo, double hi, int points, bool kv) {
 }
 
 
+// Per-pass times of `runs` sorts of 2^lg uniform keys (fresh mt19937 data for each), median / mean / min per stage from
+// the 15-slot timestamp contract -- the per-pass parity table of profiles/r04_kv_pass_parity.txt.  Run under
+// `rocprofv3 --kernel-trace` the same command gives the kernels' own durations (tools/pass_parity.py groups them).
+void Passes(Harness& h, int lg, bool kv, int runs) {
+  const uint32_t n = 1u << lg;
+  const uint32_t inout = Align16(n * 4u);
+  VrdxSorterStorageRequirements req;
+  vrdxGetSorterKeyValueStorageRequirements(h.sorter, n, &req);
+  h.reserve((size_t)2 * inout + 16, (size_t)req.size + StorageOffset());
+  std::vector<uint64_t> stage[6];
+  for (int run = 0; run <= runs; ++run) {
+    std::vector<uint32_t> v;
+    auto k = Mt(n, run + 1, 32, &v);
+    HIP_OK(hipMemcpy(h.dKeys, k.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(h.dKeys + inout, v.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipDeviceSynchronize());
+    if (kv)
+      vrdxCmdSortKeyValue((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dKeys, inout,
+                          (VkBuffer)h.dStorage, StorageOffset(), h.pool, 0);
+    else
+      vrdxCmdSort((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dStorage, StorageOffset(), h.pool, 0);
+    HIP_OK(hipStreamSynchronize(h.stream));
+    uint64_t ts[15];
+    if (vrdxHipGetQueryPoolResults(h.pool, 0, 15, ts) != VK_SUCCESS) std::exit(3);
+    if (run == 0) continue;
+    stage[0].push_back(ts[2] - ts[1]);
+    for (int p = 0; p < 4; ++p) stage[1 + p].push_back(ts[4 + 3 * p] - ts[3 + 3 * p]);
+    stage[5].push_back(ts[14]);
+  }
+  const char* names[6] = {"histogram", "pass 0", "pass 1", "pass 2", "pass 3", "whole sort"};
+  std::printf("n=%u %s storage offset %llu, %d runs (us: median mean min)\n", n, kv ? "kv" : "keys",
+              (unsigned long long)StorageOffset(), runs);
+  for (int s = 0; s < 6; ++s) {
+    double mean = 0;
+    for (uint64_t t : stage[s]) mean += (double)t;
+    mean /= (double)stage[s].size();
+    std::printf("  %-10s %8.2f %8.2f %8.2f\n", names[s], Median(stage[s]) / 1e3, mean / 1e3,
+                *std::min_element(stage[s].begin(), stage[s].end()) / 1e3);
+  }
+}
+
 // BASELINE.json configs[3]: N = 2^25 adversarial keys (all-equal, all-0xFFFFFFFF, descending,
 // few-distinct) against uniform random; values = iota, parity checked with the oracle for the
 // stable permutation, then timed (median of 5, data re-uploaded before every run).
@@ -479,7 +537,7 @@ int Adversarial(Harness& h, int lg) {
   const uint32_t inout = Align16(n * 4u);
   VrdxSorterStorageRequirements req;
   vrdxGetSorterKeyValueStorageRequirements(h.sorter, n, &req);
-  h.reserve((size_t)2 * inout + 16, (size_t)req.size);
+  h.reserve((size_t)2 * inout + 16, (size_t)req.size + StorageOffset());
   std::vector<uint32_t> iota(n), k(n);
   for (uint32_t i = 0; i < n; ++i) iota[i] = i;
   std::mt19937 g(4);
@@ -491,7 +549,9 @@ int Adversarial(Harness& h, int lg) {
   double base[2] = {0, 0};
   int failures = 0;
   std::printf("%-18s %-5s %10s %12s %10s %s\n", "keys", "sort", "gpu_ms", "GItems/s", "slowdown", "parity");
-  for (int pattern = 0; pattern < 8; ++pattern) {
+  const char* const patternsEnv = std::getenv("VRDX_SELFTEST_PATTERNS");  // the first k input patterns only
+  const int patterns = patternsEnv != nullptr ? std::min(8, std::max(1, std::atoi(patternsEnv))) : 8;
+  for (int pattern = 0; pattern < patterns; ++pattern) {
     const uint32_t four[4] = {3u, 0xFFFFFFFFu, 0x00010000u, 0x7F000000u};
     for (uint32_t i = 0; i < n; ++i) {
       switch (pattern) {
@@ -517,9 +577,9 @@ int Adversarial(Harness& h, int lg) {
         HIP_OK(hipDeviceSynchronize());
         if (kv)
           vrdxCmdSortKeyValue((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dKeys, inout,
-                              (VkBuffer)h.dStorage, 0, h.pool, 0);
+                              (VkBuffer)h.dStorage, StorageOffset(), h.pool, 0);
         else
-          vrdxCmdSort((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dStorage, 0, h.pool, 0);
+          vrdxCmdSort((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dStorage, StorageOffset(), h.pool, 0);
         HIP_OK(hipStreamSynchronize(h.stream));
         uint64_t ts[15];
         if (vrdxHipGetQueryPoolResults(h.pool, 0, 15, ts) != VK_SUCCESS) return 3;
@@ -533,7 +593,7 @@ int Adversarial(Harness& h, int lg) {
           HIP_OK(hipMemcpy(gk.data(), h.dKeys, (size_t)n * 4, hipMemcpyDeviceToHost));
           HIP_OK(hipMemcpy(gv.data(), h.dKeys + inout, (size_t)n * 4, hipMemcpyDeviceToHost));
           ok = gk == ek && (!kv || gv == ev);
-          if (vrdxHipReadStatus((VkCommandBuffer)h.stream, (VkBuffer)h.dStorage, 0) != 0) ok = false;
+          if (vrdxHipReadStatus((VkCommandBuffer)h.stream, (VkBuffer)h.dStorage, StorageOffset()) != 0) ok = false;
         }
       }
       const double ms = Median(times) / 1e6;
@@ -656,6 +716,10 @@ int main(int argc, char** argv) {
           argc > 5 && std::string(argv[5]) == "kv");
     return 0;
   }
+  if (what == "passes") {  // passes <log2n> [keys|kv] [runs]
+    Passes(h, argc > 2 ? std::atoi(argv[2]) : 25, argc > 3 && std::string(argv[3]) == "kv", argc > 4 ? std::atoi(argv[4]) : 20);
+    return 0;
+  }
   if (what == "soak") return Soak(h, argc > 2 ? std::atoi(argv[2]) : 30) ? 1 : 0;
   if (what == "adversarial") return Adversarial(h, argc > 2 ? std::atoi(argv[2]) : 25) ? 1 : 0;
   if (what == "bench") {
@@ -665,6 +729,6 @@ int main(int argc, char** argv) {
     Bench(h, logs);
     return 0;
   }
-  std::fprintf(stderr, "usage: %s parity|quick|bench [log2n...]|adversarial [log2n]|soak [s]|sweep lo hi points [kv]|trace\n", argv[0]);
+  std::fprintf(stderr, "usage: %s parity|quick|bench [log2n...]|adversarial [log2n]|soak [s]|sweep lo hi points [kv]|passes log2n [keys|kv] [runs]|trace\n", argv[0]);
   return 64;
 }

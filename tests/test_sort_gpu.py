@@ -446,14 +446,13 @@ def test_device_failure_is_sticky_in_the_sorter_status(torch_mod):
 @pytest.mark.parametrize("n", [20_000, 300_000, 1_500_000, (1 << 21), 3_500_001, 3_700_001, 6_000_001, 7_600_000])
 def test_hybrid_plan_and_its_fallback_at_the_bucket_capacity(torch_mod, sorter, oracle, n):
     """Mid-size sorts record the hybrid plan (scatter by the top byte, then one workgroup per bucket); the DEVICE
-    keeps the four passes when a bucket exceeds the capacity (4096 / 8192 / 16384, twice the mean; the largest one --
-    32768 keys-only, 16384 key+value -- is recorded up to a mean bucket of capacity / 1.1: 7.6 M keys, 3.8 M pairs).
+    keeps the four passes when a bucket exceeds the capacity (4096 / 8192 / 16384, twice the mean; the largest one,
+    32768 -- key+value stages keys and values through one buffer there -- is recorded up to a mean bucket of
+    capacity / 1.1: 7.6 M elements).
     Uniform keys with ONE top byte brought to exactly the capacity (plan applies) and to capacity + 1 (four passes),
     keys-only and key+value (values = iota: the permutation itself), direct and indirect with a smaller count."""
     need = 2 * ((n + 255) // 256)
-    cap = 4096 if need <= 4096 else 8192 if need <= 8192 else 16384 if need <= 16384 else 32768   # (the last: keys-only)
-    if n == 3_700_001:
-        cap = 16384   # the key+value capacity at this size (mean 14454)
+    cap = 4096 if need <= 4096 else 8192 if need <= 8192 else 16384 if need <= 16384 else 32768
     rng = np.random.default_rng(n)
     iota = np.arange(n, dtype=np.uint32)
     for heavy in (cap, cap + 1):

@@ -163,7 +163,7 @@ int TuningKnob(const char* name) {
 // bucket twice the room of its mean N / 256; the largest one is recorded as long as it leaves 10 % (a bucket sort
 // costs what the bucket's elements cost, whatever the capacity; uniform keys spread by a fraction of a percent at
 // these sizes, and a plan that does not apply costs one empty launch, 3 us, where one that does saves 17-25 %):
-// N <= 7.6 M keys-only, 3.8 M key+value.  0 = the plan is not recorded (larger N, a forced tile geometry, VRDX_HYBRID=0).
+// N <= 7.6 M elements (3.8 M with the ballot ranking).  0 = the plan is not recorded (larger N, a forced tile geometry, VRDX_HYBRID=0).
 uint32_t HybridCapacity(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount) {
   static const bool enabled = [] {
     const char* env = std::getenv("VRDX_HYBRID");  // "0": always the four-pass plan (testing / measurements)
@@ -177,7 +177,10 @@ uint32_t HybridCapacity(const VrdxSorter_T* sorter, bool keyValue, uint32_t elem
   const uint64_t mean = (elementCount + VRDX_RADIX - 1) / VRDX_RADIX;
   const uint32_t need = (uint32_t)(mean * (uint64_t)(knob > 0 ? knob : 200) / 100u);
   const uint32_t needLast = (uint32_t)(mean * (uint64_t)(knobLast > 0 ? knobLast : 110) / 100u);
-  const uint32_t largest = !keyValue && sorter->atomicRank ? 32768u : 16384u;
+  // 32768-element buckets: the one-atomic ranking only (the ballot forms of that kernel would spill); key+value stages
+  // keys and values through one buffer there (SharedStage in vrdx_kernels.hip)
+  (void)keyValue;
+  const uint32_t largest = sorter->atomicRank ? 32768u : 16384u;
   if (need <= 4096u) return 4096u;
   if (need <= 8192u) return 8192u;
   if (need <= 16384u) return 16384u;
@@ -232,25 +235,21 @@ void StampSame(VrdxHipQueryPool* pool, uint32_t slot, uint32_t same) {
   pool->source[slot] = pool->source[same];
 }
 
-// Even-split tiles.  The 1024x32 kernels hold one workgroup per CU, so a sort of T tiles takes ceil(T / CUs) rounds
-// however full the last round is: 257 tiles cost two rounds, and so do 512.  When the sort is no more than
-// kEvenSplitRounds rounds long it is cut into rounds * CUs EQUAL tiles instead (a multiple of four 64-key slots per
-// wave), which the kernels' even-split forms (OnesweepArgs::slots) walk with loops of that length.  Returns the slots
-// per wave, or 0 for tiles of the kernel's full capacity.  VRDX_EVEN_SPLIT=0 turns it off (measurements).
-constexpr uint32_t kEvenSplitRounds = 1;
-uint32_t EvenSplitSlots(const VrdxSorter_T* sorter, int configIndex, bool keyValue, uint32_t elementCount) {
-  static const int knob = TuningKnob("VRDX_EVEN_SPLIT");        // 0: off; r > 0: up to r rounds
-  if (knob == 0 || keyValue || (configIndex != kCfg1024x32 && configIndex != kCfg1024x32x2)) return 0;
-  const uint32_t maxRounds = knob > 0 ? (uint32_t)knob : kEvenSplitRounds;
+// The tile plan of a sort (vrdx_layout.h, PlanTiles): even-split tiles for sorts of one round, tail-split tiles behind
+// the whole rounds of a longer one.  VRDX_EVEN_SPLIT=0 / VRDX_TAIL_SPLIT=0 turn them off, VRDX_TAIL_SPLIT=p limits the
+// tail split to rests of at most p % of a round (measurements).
+bool SplitFormsBuilt(int configIndex, bool keyValue, bool atomicRank) {
+  if (configIndex == kCfg1024x32x2) return !keyValue && atomicRank;
+  return configIndex == kCfg1024x32;
+}
+
+vrdx::TilePlan PlanTiles(const VrdxSorter_T* sorter, int configIndex, bool keyValue, uint32_t elementCount) {
+  static const int evenKnob = TuningKnob("VRDX_EVEN_SPLIT");
+  static const int tailKnob = TuningKnob("VRDX_TAIL_SPLIT");
   const vrdx::TileConfig& c = vrdx::kTileConfigs[configIndex];
-  const uint32_t cus = (uint32_t)sorter->computeUnits;
-  const uint32_t rounds = vrdx::RoundUp(vrdx::RoundUp(elementCount, c.tileKeys()), cus);
-  if (rounds == 0 || rounds > maxRounds) return 0;
-  const uint32_t granule = 4u * (uint32_t)c.threads * (uint32_t)c.subTiles;  // four slots per wave (and sub-tile)
-  const uint32_t perTile = vrdx::RoundUp(elementCount, rounds * cus);
-  uint32_t slots = 4u * vrdx::RoundUp(perTile, granule);
-  if (slots < 8u) slots = 8u;  // status rows fit the reference's storage for tiles of 8192 keys and more (vrdx_layout.h)
-  return slots >= (uint32_t)c.keysPerThread ? 0u : slots;
+  return vrdx::PlanTiles(elementCount, (uint32_t)sorter->computeUnits, (uint32_t)c.threads, (uint32_t)c.keysPerThread,
+                         (uint32_t)c.subTiles, SplitFormsBuilt(configIndex, keyValue, sorter->atomicRank), evenKnob != 0,
+                         tailKnob < 0 ? vrdx::kTailSplitPercent : (uint32_t)tailKnob);
 }
 
 // reference: gpuSort, src/vk_radix_sort.h.in:344-507
@@ -279,12 +278,10 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   } deviceScope(sorter->device);
 
   const int configIndex = ConfigIndex(sorter, keyValue, elementCount);
-  const uint32_t evenSlots = EvenSplitSlots(sorter, configIndex, keyValue, elementCount);
-  const uint32_t tileKeys = evenSlots != 0 ? evenSlots * 1024u * (uint32_t)vrdx::kTileConfigs[configIndex].subTiles
-                                           : vrdx::kTileConfigs[configIndex].tileKeys();
-  const vrdx::StorageLayout layout =
-      vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, tileKeys);
+  const vrdx::TilePlan tilePlan = PlanTiles(sorter, configIndex, keyValue, elementCount);
   uint8_t* const storage = BufferAddress(storageBuffer, storageOffset);
+  const vrdx::StorageLayout layout = vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment,
+                                                      tilePlan.tiles, (uint64_t)reinterpret_cast<uintptr_t>(storage));
   uint32_t* const keys = reinterpret_cast<uint32_t*>(BufferAddress(keysBuffer, keysOffset));
   uint32_t* const values =
       keyValue ? reinterpret_cast<uint32_t*>(BufferAddress(valuesBuffer, valuesOffset)) : nullptr;
@@ -352,7 +349,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
                  vrdx::LaunchHistogram(stream, grid, keys, elementCount, countPtr, globalHistogram, tickets));
   }
 
-  const uint32_t tiles = vrdx::RoundUp(elementCount, tileKeys);
+  const uint32_t tiles = tilePlan.tiles;
   const uint32_t hybridCap = ForcedConfigIndex() < 0 ? HybridCapacity(sorter, keyValue, elementCount) : 0u;
   // Key+value tiles fetch their values early (right after the ranking: they land during the scan and the
   // regroup) -- on the final kernels that is as fast as or faster than fetching them after the
@@ -415,7 +412,9 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     if (testSpinLimit >= 0) args.spinLimit = (uint32_t)testSpinLimit;
 #endif
     args.earlyValues = earlyValues ? 1u : 0u;
-    args.slots = evenSlots;
+    args.slots = tilePlan.slots;
+    args.fullTiles = tilePlan.fullTiles;
+    args.tailSlots = tilePlan.tailSlots;
     args.trace = nullptr;
 #ifdef VRDX_TRACE
     args.trace = TraceBuffer(pass, tiles);
@@ -505,8 +504,7 @@ void vrdxDestroySorter(VrdxSorter sorter) {
 void vrdxGetSorterStorageRequirements(VrdxSorter sorter, uint32_t maxElementCount,
                                       VrdxSorterStorageRequirements* requirements) {
   const vrdx::StorageLayout layout =
-      vrdx::MakeLayout(maxElementCount, sorter->minStorageBufferOffsetAlignment,
-                       vrdx::kTileConfigs[ConfigIndex(sorter, false, maxElementCount)].tileKeys());
+      vrdx::MakeLayout(maxElementCount, sorter->minStorageBufferOffsetAlignment, 0);  // the size is the reference's formula
   requirements->size = layout.keysOnlySize;
   requirements->usage = VK_BUFFER_USAGE_STORAGE_BUFFER_BIT | VK_BUFFER_USAGE_TRANSFER_DST_BIT;
 }
@@ -514,8 +512,7 @@ void vrdxGetSorterStorageRequirements(VrdxSorter sorter, uint32_t maxElementCoun
 void vrdxGetSorterKeyValueStorageRequirements(VrdxSorter sorter, uint32_t maxElementCount,
                                               VrdxSorterStorageRequirements* requirements) {
   const vrdx::StorageLayout layout =
-      vrdx::MakeLayout(maxElementCount, sorter->minStorageBufferOffsetAlignment,
-                       vrdx::kTileConfigs[ConfigIndex(sorter, true, maxElementCount)].tileKeys());
+      vrdx::MakeLayout(maxElementCount, sorter->minStorageBufferOffsetAlignment, 0);
   requirements->size = layout.keyValueSize;
   requirements->usage = VK_BUFFER_USAGE_STORAGE_BUFFER_BIT | VK_BUFFER_USAGE_TRANSFER_DST_BIT;
 }

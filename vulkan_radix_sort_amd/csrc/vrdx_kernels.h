@@ -45,6 +45,10 @@ struct TileConfig {
 constexpr int kNumTileConfigs = 4;
 extern const TileConfig kTileConfigs[kNumTileConfigs];
 
+// Tail split (vrdx_layout.h, PlanTiles): applied while what is left behind the whole rounds is at most this share of a
+// round (profiles/r04_tail_split.txt).
+constexpr uint32_t kTailSplitPercent = 100;
+
 // Every spin is bounded: a look-back that makes no progress for this many trips sets the failure word and goes on
 // (result unspecified) instead of hanging the GPU.
 constexpr uint32_t kSpinLimit = 1u << 18;
@@ -71,7 +75,10 @@ struct OnesweepArgs {
   uint32_t hybridCap;         // 0, or the bucket capacity of the hybrid plan recorded with this sort (PassPlan)
   uint32_t spinLimit;         // look-back trips without progress before the tile gives up (kSpinLimit)
   uint32_t earlyValues;       // KV: fetch the values right after the ranking instead of after the look-back
-  uint32_t slots;             // 0, or even-split tiles: slots of 64 keys per wave (and sub-tile), a multiple of 4 (PlanTiles)
+  uint32_t slots;             // 0: every tile holds the kernel's capacity; otherwise (PlanTiles) the first fullTiles tiles take
+                              // `slots` slots of 64 keys per wave (and sub-tile), the tiles behind them tailSlots (multiples of 4)
+  uint32_t fullTiles;
+  uint32_t tailSlots;
   unsigned long long* trace;  // phase stamps, 8 per tile; nullptr outside tools/trace.sh builds
   uint32_t* planWord;         // hybridCap != 0: the verdict word in the storage (VRDX_OFF_PLAN), written by launch 0
                               // (last on purpose: the argument layout of the kernels that never read it stays as it was)

@@ -440,6 +440,30 @@ __device__ __forceinline__ uint32_t QuadSum(uint32_t v) {
 // onesweep: rank + decoupled look-back + scatter, one launch per pass
 // ---------------------------------------------------------------------------------------------
 
+// Which keys a tile covers.  Tiles are numbered by ticket; tile i < fullTiles holds slotsA slots of 64 keys per wave
+// (times `lanesPerSlot` = threads, or two sub-tiles' worth), the tiles behind them slotsB -- PlanTiles in vrdx_api.cpp:
+// whole rounds of full tiles, then one round of small equal tiles for the rest, so that the last, partial round of a
+// sort costs what its keys cost.  fullTiles = ~0u: every tile alike.  All wave-uniform (scalar registers).
+struct TileSpan {
+  uint32_t start;   // first key
+  uint32_t slots;   // slots per wave (and sub-tile) of this tile
+  bool last;        // the tile that holds key n - 1: never looked at, publishes nothing
+  bool beyond;      // starts at or behind n: nothing to do
+};
+__device__ __forceinline__ TileSpan SpanOfTile(uint32_t tile, uint32_t n, uint32_t slotsA, uint32_t slotsB,
+                                               uint32_t fullTiles, uint32_t lanesPerSlot) {
+  TileSpan s;
+  const uint32_t frameA = slotsA * lanesPerSlot, frameB = slotsB * lanesPerSlot;
+  const bool tail = tile >= fullTiles;
+  const uint32_t keysA = tail ? fullTiles * frameA : 0u;
+  const uint32_t frame = tail ? frameB : frameA;
+  s.slots = tail ? slotsB : slotsA;
+  s.start = keysA + (tail ? tile - fullTiles : tile) * frame;
+  s.beyond = s.start >= n;
+  s.last = !s.beyond && n - s.start <= frame;
+  return s;
+}
+
 // Measured (tools/trace.sh, profiles/): agent-scope (sc1) status reads cost a CU roughly 13 GB/s,
 // independent of the access width (16-byte row loads were SLOWER: 2.9 us per 4-row trip against
 // 1.5 us per 8-row trip of 4-byte loads), a tile walks ~49 rows = 49 KiB before it meets an
@@ -926,10 +950,11 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
 
   // Launches 1-3 of a sort whose hybrid plan applies have nothing to do, and launch 0 has said so in one word: they
   // return after one load instead of after the table, the ticket, the votes and a barrier (4 -> 2 us per empty launch).
-  // (Not compiled into the key+value 1024x32 form: the hybrid plan is never recorded with it on a 256-CU device -- it
-  // ends at 3.8 M pairs, that geometry starts at 4.4 M -- and the two lines cost that kernel two registers and 1.7 %
-  // at 2^25, measured.  On a device where the two do meet, its launches take the long way to the same verdict.)
-  constexpr bool kVerdictWord = !(KV && KPT == 32);
+  // (Not compiled into the key+value 1024x32 form with tiles of full capacity, the kernel of the 2^25 headline: the two
+  // lines cost it two registers and 1.7 % there, measured.  The hybrid plan ends at 7.6 M pairs, i.e. inside one round
+  // of tiles, where key+value sorts run the form with run-time slot counts (even-split tiles) of this geometry; a sort
+  // that does meet the full-capacity form with a hybrid plan recorded takes the long way to the same verdict.)
+  constexpr bool kVerdictWord = !(KV && KPT == 32 && !DYN);
   if constexpr (kVerdictWord) {
     if (a.hybridCap != 0 && a.pass != 0 && *a.planWord == 1u) return;
   }
@@ -963,12 +988,14 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
     }
     return;
   }
-  const uint32_t slots = DYN ? a.slots : (uint32_t)KPT;  // per wave
-  const uint32_t frame = slots * THREADS;                // keys per tile (TILE unless DYN)
-  const uint32_t tiles = (n + frame - 1) / frame;
-  if (tile >= tiles) return;  // uniform for the whole workgroup
-  const bool lastTile = tile == tiles - 1;
-  const uint32_t tileStart = tile * frame;
+  // DYN: the first a.fullTiles tiles take a.slots slots per wave, the tiles behind them a.tailSlots (PlanTiles)
+  const TileSpan span = DYN ? SpanOfTile(tile, n, a.slots, a.tailSlots, a.fullTiles, THREADS)
+                            : SpanOfTile(tile, n, (uint32_t)KPT, (uint32_t)KPT, ~0u, THREADS);
+  if (span.beyond) return;  // uniform for the whole workgroup
+  const uint32_t slots = DYN ? span.slots : (uint32_t)KPT;  // per wave
+  const uint32_t frame = slots * THREADS;                   // keys this tile can hold (TILE unless DYN)
+  const bool lastTile = span.last;
+  const uint32_t tileStart = span.start;
   const uint32_t valid = (n - tileStart) < frame ? (n - tileStart) : frame;
   const uint32_t tileEnd = tileStart + valid;
 
@@ -1010,7 +1037,10 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
     RankBallot<KPT, PACKED, DYN>(key, shift, waveHist + wave * 256, lane, rank, slots);
   ForgetDerivedValues<KPT>(key);
   // key+value, early form: the values start their trip now and land during the scan and the regroup
-  if constexpr (KV) {
+  // (The form with run-time slot counts always fetches them late: its loops end in branches, the values would be live
+  // across all of them and the kernel would need 140 registers -- 48 bytes of scratch per lane, 5-10 % slower, round 3.)
+  constexpr bool kEarlyValuesBuilt = KV && !DYN;
+  if constexpr (kEarlyValuesBuilt) {
     if (a.earlyValues) LoadTile<KPT, DYN>(valuesIn, loadBase, tileEnd, valid == frame, 0u, val, streaming, slots);  // pad: downsweep.slang:85
   }
   LdsBarrier();
@@ -1068,7 +1098,8 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   // of tiles; on the final kernels the early form is as fast or faster everywhere.  Issued right
   // before the look-back the loads queue in front of its agent-scope status reads (6 -> 9 us, measured).
   if constexpr (KV) {
-    if (!a.earlyValues) LoadTile<KPT, DYN>(valuesIn, loadBase, tileEnd, valid == frame, 0u, val, streaming, slots);
+    if (!kEarlyValuesBuilt || !a.earlyValues)
+      LoadTile<KPT, DYN>(valuesIn, loadBase, tileEnd, valid == frame, 0u, val, streaming, slots);
   }
 
   // ---- scatter (ScatterStagedKeys above); key+value replays the permutation for the values ------
@@ -1180,12 +1211,14 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
     }
     return;
   }
-  const uint32_t slots = DYN ? a.slots : (uint32_t)KPT;  // per wave and sub-tile
-  const uint32_t sub = slots * THREADS;                  // keys per sub-tile (SUB unless DYN)
-  const uint32_t tiles = (n + 2 * sub - 1) / (2 * sub);
-  if (tile >= tiles) return;  // uniform for the whole workgroup
-  const bool lastTile = tile == tiles - 1;
-  const uint32_t tileStart = tile * (2 * sub);
+  // DYN: the first a.fullTiles tiles take a.slots slots per wave and sub-tile, the tiles behind them a.tailSlots
+  const TileSpan span = DYN ? SpanOfTile(tile, n, a.slots, a.tailSlots, a.fullTiles, 2 * THREADS)
+                            : SpanOfTile(tile, n, (uint32_t)KPT, (uint32_t)KPT, ~0u, 2 * THREADS);
+  if (span.beyond) return;  // uniform for the whole workgroup
+  const uint32_t slots = DYN ? span.slots : (uint32_t)KPT;  // per wave and sub-tile
+  const uint32_t sub = slots * THREADS;                     // keys per sub-tile (SUB unless DYN)
+  const bool lastTile = span.last;
+  const uint32_t tileStart = span.start;
   const uint32_t left = n - tileStart;
   const uint32_t validA = left < sub ? left : sub;
   const uint32_t validB = left > sub ? (left - sub < sub ? left - sub : sub) : 0u;
@@ -1331,9 +1364,17 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
 // wave-striped order.  No global histogram, no tickets, no status words; of the storage only the failure word is written.
 // Positions >= n hold 0xFFFFFFFF pads (value 0): they are last in memory order and carry the
 // largest key, so the stable sort leaves them behind the n real elements, which are what is stored.
+// Key+value with THREADS * KPT = 32768 elements: two staging buffers of that size do not fit the CU's LDS, so keys and
+// values take turns in ONE (like the pass kernels, and like the reference, downsweep.slang:208-224): two more barriers
+// per pass, the same LDS traffic.
+template <int THREADS, int KPT, bool KV>
+constexpr bool SharedStage() {
+  return KV && (size_t)THREADS * KPT * 2 * 4 + (size_t)(THREADS / 64) * 1024 + 64 > 160 * 1024;
+}
+
 template <int THREADS, int KPT, bool KV>
 constexpr size_t SmallSortLdsWords() {
-  return (size_t)THREADS * KPT * (KV ? 2 : 1) + (size_t)(THREADS / 64) * 256 + 16;
+  return (size_t)THREADS * KPT * (KV && !SharedStage<THREADS, KPT, KV>() ? 2 : 1) + (size_t)(THREADS / 64) * 256 + 16;
 }
 
 // The sort of n <= THREADS * KPT elements by the key bytes [0, bytes) inside one workgroup: in[0..n) -> out[0..n)
@@ -1346,10 +1387,11 @@ __device__ __forceinline__ void SortInWorkgroup(const uint32_t* keysIn, uint32_t
                                                 uint32_t* valuesOut, uint32_t n, uint32_t bytes, uint32_t* smem) {
   constexpr int WAVES = THREADS / 64;
   constexpr uint32_t TILE = THREADS * KPT;
-  uint32_t* const stagedKeys = smem;                              // TILE
-  uint32_t* const stagedValues = smem + TILE;                     // TILE (key+value)
-  uint32_t* const waveHist = smem + TILE * (KV ? 2 : 1);          // WAVES x 256
-  uint32_t* const scanScratch = waveHist + WAVES * 256;           // 8
+  constexpr bool SHARED = SharedStage<THREADS, KPT, KV>();
+  uint32_t* const stagedKeys = smem;                                  // TILE
+  uint32_t* const stagedValues = SHARED ? smem : smem + TILE;         // TILE (key+value)
+  uint32_t* const waveHist = smem + TILE * (KV && !SHARED ? 2 : 1);   // WAVES x 256
+  uint32_t* const scanScratch = waveHist + WAVES * 256;               // 8
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1368,16 +1410,24 @@ __device__ __forceinline__ void SortInWorkgroup(const uint32_t* keysIn, uint32_t
   LoadStriped<KPT, false, DYN>(keysIn, first, n, n >= slots * THREADS, 0xFFFFFFFFu, key, slots);  // pad: downsweep.slang:81
   if constexpr (KV) LoadStriped<KPT, false, DYN>(valuesIn, first, n, n >= slots * THREADS, 0u, val, slots);  // pad: downsweep.slang:85
 
+  // SHARED: ranks, then staging slots, two to a register (< TILE <= 65536): keys, values and positions of 32 elements
+  // per lane have to fit 128 registers
+  constexpr bool PACKED = SHARED;
+  static_assert(!PACKED || TILE <= 65536, "packed 16-bit positions");
 #pragma unroll 1
   for (uint32_t shift = 0; shift < 8 * bytes; shift += 8) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) myHist[lane + 64 * i] = 0;  // my own row: no barrier needed before ranking
-    uint32_t rank[KPT];
+    uint32_t rank[PACKED ? KPT / 2 : KPT];
     if constexpr (ATOMIC_RANK)
-      RankAtomic<KPT, false, DYN>(key, shift, myHist, lane, rank, slots);
+      RankAtomic<KPT, PACKED, DYN>(key, shift, myHist, lane, rank, slots);
     else
-      RankBallot<KPT, false, DYN>(key, shift, myHist, lane, rank, slots);
+      RankBallot<KPT, PACKED, DYN>(key, shift, myHist, lane, rank, slots);
     LdsBarrier();
+    // The read-back addresses below do not depend on the pass: left alone the compiler computes all KPT of them once,
+    // in front of the loop, and keeps them in registers through every pass (the 32768-element key+value form then spills).
+    uint32_t firstNow = first;
+    asm volatile("" : "+v"(firstNow));
 
     uint32_t count = 0;
     if (tid < 256) {
@@ -1396,22 +1446,63 @@ __device__ __forceinline__ void SortInWorkgroup(const uint32_t* keysIn, uint32_t
     }
     LdsBarrier();
 
+    if constexpr (SHARED) {
+      // keys through the buffer, then the values through the same slots
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-      if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
-      const uint32_t slot = StagingSlot<TILE>(rank[i] + myHist[(key[i] >> shift) & 0xFFu]);
-      stagedKeys[slot] = key[i];
-      if constexpr (KV) stagedValues[slot] = val[i];
-    }
-    LdsBarrier();
+      for (int base = 0; base < KPT; base += 4) {
+        if (DYN && (uint32_t)base >= slots) break;
+        uint32_t p[4];
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-      if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
-      const uint32_t slot = StagingSlot<TILE>(first + 64 * i);
-      key[i] = stagedKeys[slot];
-      if constexpr (KV) val[i] = stagedValues[slot];
+        for (int c = 0; c < 4; ++c) p[c] = myHist[(key[base + c] >> shift) & 0xFFu];  // four reads in flight, then four stores
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int i = base + c;
+          p[c] = StagingSlot<TILE>(p[c] + ((rank[i / 2] >> (16 * (i % 2))) & 0xFFFFu));
+          stagedKeys[p[c]] = key[i];
+          if (c % 2 == 1) {
+            rank[i / 2] = p[c - 1] | (p[c] << 16);
+            asm volatile("" : "+v"(rank[i / 2]));  // pack now, not when first used
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one chunk at a time: hoisting every counter read costs registers this kernel lacks
+      }
+      LdsBarrier();
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
+        key[i] = stagedKeys[StagingSlot<TILE>(firstNow + 64 * i)];
+      }
+      LdsBarrier();
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
+        stagedValues[(rank[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
+      }
+      LdsBarrier();
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
+        val[i] = stagedValues[StagingSlot<TILE>(firstNow + 64 * i)];
+      }
+      // the next pass writes the staging buffer only after two more barriers
+    } else {
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
+        const uint32_t slot = StagingSlot<TILE>(rank[i] + myHist[(key[i] >> shift) & 0xFFu]);
+        stagedKeys[slot] = key[i];
+        if constexpr (KV) stagedValues[slot] = val[i];
+      }
+      LdsBarrier();
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
+        const uint32_t slot = StagingSlot<TILE>(firstNow + 64 * i);
+        key[i] = stagedKeys[slot];
+        if constexpr (KV) val[i] = stagedValues[slot];
+      }
+      // the next pass writes the staging buffers only after two more barriers
     }
-    // the next pass writes the staging buffers only after two more barriers
   }
 
 #pragma unroll
@@ -1465,7 +1556,10 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(BucketSortArgs a) 
     smem[9] = count;
   }
   LdsBarrier();
-  const uint32_t myBase = smem[8], myCount = smem[9];
+  // (read from LDS, so the compiler takes them for per-lane values: as scalars the four array bases stay out of the
+  // vector registers, which the 32768-element key+value form has none to spare of)
+  const uint32_t myBase = (uint32_t)__builtin_amdgcn_readfirstlane((int)smem[8]);
+  const uint32_t myCount = (uint32_t)__builtin_amdgcn_readfirstlane((int)smem[9]);
   LdsBarrier();  // smem is the sort's from here on
   if (myCount == 0) return;  // uniform
   SortInWorkgroup<THREADS, KPT, KV, ATOMIC_RANK>(a.keysScratch + myBase, a.keysCaller + myBase,
@@ -1550,9 +1644,8 @@ static const void* PairKernel() {
   return reinterpret_cast<const void*>(&onesweep_pair_kernel<THREADS, KPT, DYN>);
 }
 
-// EVEN: the even-split forms (args.slots != 0) are built for this geometry as well -- keys-only: the key+value
-// kernel with run-time loop bounds needs 12 registers more than the 128 of four waves per SIMD (48 bytes of scratch
-// per lane, 5-10 % slower than full tiles; profiles/r03_even_split.txt), so key+value sorts keep tiles of full capacity.
+// EVEN: the forms with run-time slot counts (args.slots != 0: even-split and tail-split tiles, PlanTiles in
+// vrdx_api.cpp) are built for this geometry as well.
 template <int THREADS, int KPT, bool EVEN = false>
 static hipError_t PrepareConfig() {
   const int keysBytes = (int)(OnesweepLdsWords<THREADS, KPT, false>() * sizeof(uint32_t));
@@ -1560,15 +1653,17 @@ static hipError_t PrepareConfig() {
   const struct {
     const void* fn;
     int bytes;
-  } kernels[6] = {
+  } kernels[8] = {
       {OnesweepKernel<THREADS, KPT, false, false>(), keysBytes},
       {OnesweepKernel<THREADS, KPT, false, true>(), keysBytes},
       {OnesweepKernel<THREADS, KPT, true, false>(), kvBytes},
       {OnesweepKernel<THREADS, KPT, true, true>(), kvBytes},
       {OnesweepKernel<THREADS, KPT, false, false, EVEN>(), keysBytes},
       {OnesweepKernel<THREADS, KPT, false, true, EVEN>(), keysBytes},
+      {OnesweepKernel<THREADS, KPT, true, false, EVEN>(), kvBytes},
+      {OnesweepKernel<THREADS, KPT, true, true, EVEN>(), kvBytes},
   };
-  for (int i = 0; i < (EVEN ? 6 : 4); ++i) {
+  for (int i = 0; i < (EVEN ? 8 : 4); ++i) {
     const hipError_t e = hipFuncSetAttribute(kernels[i].fn, hipFuncAttributeMaxDynamicSharedMemorySize, kernels[i].bytes);
     if (e != hipSuccess) return e;
   }
@@ -1583,9 +1678,14 @@ static hipError_t LaunchConfig(hipStream_t stream, uint32_t grid, bool keyValue,
   const void* kernel =
       keyValue ? (atomicRank ? OnesweepKernel<THREADS, KPT, true, true>() : OnesweepKernel<THREADS, KPT, true, false>())
                : (atomicRank ? OnesweepKernel<THREADS, KPT, false, true>() : OnesweepKernel<THREADS, KPT, false, false>());
-  if (args.slots != 0) {  // even-split tiles
-    if (!EVEN || keyValue || args.slots % 4 != 0 || args.slots > (uint32_t)KPT) return hipErrorInvalidValue;
-    kernel = atomicRank ? OnesweepKernel<THREADS, KPT, false, true, EVEN>() : OnesweepKernel<THREADS, KPT, false, false, EVEN>();
+  if (args.slots != 0) {  // run-time slot counts
+    if (!EVEN || args.slots % 4 != 0 || args.slots > (uint32_t)KPT || args.tailSlots % 4 != 0 || args.tailSlots == 0 ||
+        args.tailSlots > (uint32_t)KPT)
+      return hipErrorInvalidValue;
+    kernel = keyValue ? (atomicRank ? OnesweepKernel<THREADS, KPT, true, true, EVEN>()
+                                    : OnesweepKernel<THREADS, KPT, true, false, EVEN>())
+                      : (atomicRank ? OnesweepKernel<THREADS, KPT, false, true, EVEN>()
+                                    : OnesweepKernel<THREADS, KPT, false, false, EVEN>());
   }
   return Launch(kernel, grid, THREADS, lds, stream, args);
 }
@@ -1608,8 +1708,10 @@ static hipError_t LaunchPairConfig(hipStream_t stream, uint32_t grid, bool keyVa
                                    const OnesweepArgs& args) {
   if (keyValue || !atomicRank) return hipErrorInvalidValue;  // never selected (ConfigIndex)
   const size_t lds = PairLdsWords<THREADS, KPT>() * sizeof(uint32_t);
-  if (args.slots != 0) {  // even-split tiles
-    if (args.slots % 4 != 0 || args.slots > (uint32_t)KPT) return hipErrorInvalidValue;
+  if (args.slots != 0) {  // run-time slot counts
+    if (args.slots % 4 != 0 || args.slots > (uint32_t)KPT || args.tailSlots % 4 != 0 || args.tailSlots == 0 ||
+        args.tailSlots > (uint32_t)KPT)
+      return hipErrorInvalidValue;
     return Launch(PairKernel<THREADS, KPT, true>(), grid, THREADS, lds, stream, args);
   }
   return Launch(PairKernel<THREADS, KPT>(), grid, THREADS, lds, stream, args);
@@ -1739,11 +1841,14 @@ hipError_t PrepareBucketSort() {
   hipError_t e = PrepareBucket<4>();
   if (e == hipSuccess) e = PrepareBucket<8>();
   if (e == hipSuccess) e = PrepareBucket<16>();
-  // 32768-element buckets: keys-only (two staging buffers of that size do not fit the LDS) with the one-atomic ranking
-  // (the ballot form would spill 120 bytes per lane)
+  // 32768-element buckets: with the one-atomic ranking only (the ballot forms would spill); key+value stages keys and
+  // values through ONE buffer (SharedStage)
   if (e == hipSuccess)
     e = hipFuncSetAttribute(BucketKernel<32, false, true>(), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(SmallSortLdsWords<1024, 32, false>() * 4));
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(BucketKernel<32, true, true>(), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(SmallSortLdsWords<1024, 32, true>() * 4));
   return e;
 }
 
@@ -1753,7 +1858,9 @@ hipError_t LaunchBucketSort(hipStream_t stream, bool keyValue, bool atomicRank, 
     case 1024u * 8u: return LaunchBucket<8>(stream, keyValue, atomicRank, args);
     case 1024u * 16u: return LaunchBucket<16>(stream, keyValue, atomicRank, args);
     case 1024u * 32u:
-      if (keyValue || !atomicRank) return hipErrorInvalidValue;  // never recorded (HybridCapacity)
+      if (!atomicRank) return hipErrorInvalidValue;  // never recorded (HybridCapacity)
+      if (keyValue)
+        return Launch(BucketKernel<32, true, true>(), VRDX_RADIX, 1024, SmallSortLdsWords<1024, 32, true>() * 4, stream, args);
       return Launch(BucketKernel<32, false, true>(), VRDX_RADIX, 1024, SmallSortLdsWords<1024, 32, false>() * 4, stream, args);
     default: return hipErrorInvalidValue;
   }

@@ -1,33 +1,43 @@
 // Storage layout and tile constants shared by the host recorder and the device kernels.
 //
 // The caller allocates exactly vrdxGetSorter[KeyValue]StorageRequirements().size bytes, and that
-// number is the reference's formula bit for bit (src/vk_radix_sort.h.in:105-115,279-308), so our
-// device state has to live inside the regions the reference carves (src/vk_radix_sort.h.in:353-362):
+// number is the reference's formula bit for bit (src/vk_radix_sort.h.in:105-115,279-308).  What the
+// bytes hold is unspecified scratch from the caller's point of view, so only the SIZE is kept; the
+// carving differs from the reference's (src/vk_radix_sort.h.in:353-362) in one respect since round 4:
+// everything a kernel streams through is placed on a 128-byte boundary of the ABSOLUTE address
+// (S = storage buffer + storageOffset, a multiple of 16 by the reference's contract, README.md:150).
 //
-//   byte offset from storageOffset (A = 16)         reference use             our use
-//   [0, 4)                                          element count             element count (direct)
-//   [4, 12)                                         (padding)                 unused
-//   [12, 16)                                        (padding)                 failure word
-//   [A, A+4096)                                     globalHistogram[4][256]   globalHistogram[4][256] (raw counts)
-//   [A+4096, A+4096+P*1024), P = ceil(N/4096)       partitionHistogram[P][256] tile status[2][rows][256], then
-//                                                                              (>= 1 KiB is left) tile tickets[2]
-//   16 B                                            (slack of the "4 +" term) unused
-//   inoutOffset = A + HistogramSize(N)              keys scratch uint[N]      keys scratch uint[N]
-//   inoutOffset + Align(InoutSize, A)               values scratch uint[N]    values scratch uint[N]
+//   byte offset from S (A = 16)                     reference use              our use
+//   [0, 4)                                          element count              element count (indirect: copied)
+//   [4, 8)                                          (padding)                  hybrid plan's verdict (VRDX_OFF_PLAN)
+//   [12, 16)                                        (padding)                  failure word
+//   [A, A+4096)                                     globalHistogram[4][256]    the same table (raw counts)
+//   statusOffset = first 128-byte boundary          partitionHistogram[P][256] tile status[2][rows][256]
+//                  at or behind A+4096
+//   ticketOffset = end of the status regions                                   tile tickets[2], a 128-byte line of their own
+//   inoutOffset  = ticketOffset + 128               keys scratch uint[N]       keys scratch uint[N]     (128-byte aligned)
+//   valuesOffset = inoutOffset + Align(4 N, 128)    values scratch uint[N]     values scratch uint[N]   (128-byte aligned)
 //
-// Tile status: one 32-bit word {flag:2, value:30} per (tile, digit).  A tile of VRDX_TILE keys
-// publishes its per-digit count (flag AGGREGATE) and later its inclusive prefix over all tiles
-// up to itself (flag INCLUSIVE).  The last tile is never looked at, so rows = tiles - 1, and two
-// regions (pass p uses region p & 1 and zeroes its own row of the other one for pass p + 1) need
-// 2 * (ceil(N/TILE) - 1) KiB <= P KiB, which holds for every N when TILE >= 8192.
+// Why: the reference's inoutOffset = 4128 + P * 1024 is 32 bytes past a 128-byte line for every N, so every
+// wave-striped 256-byte load of a pass that reads the scratch arrays (passes 1 and 3) touched three lines instead of
+// two: key+value passes 1 and 3 took 118-120 us instead of 113 at N = 2^25 (profiles/r04_kv_pass_parity.txt; keys-only
+// sorts do not care).  It fits: the two status regions need 2 * rows KiB <= (P - 1) KiB (see below), so at least
+// 1 KiB of the reference's partition-histogram area is free, of which the three pads (<= 124 + 112 bytes) and the
+// ticket line (128) take at most 364 bytes.
+//
+// Tile status: one 32-bit word {flag:2, value:30} per (tile, digit).  A tile publishes its per-digit count
+// (flag AGGREGATE) and later its inclusive prefix over all tiles up to itself (flag INCLUSIVE).  The last
+// tile is never looked at, so rows = tiles - 1, and two regions (pass p uses region p & 1 and zeroes its own
+// row of the other one for pass p + 1) need 2 * (tiles - 1) KiB <= (P - 1) KiB, P = ceil(N / 4096): true for
+// every N when no tile is smaller than 8192 keys, and for the tail tiles of 4096 keys and more that a sort of
+// one round and more may end with (PlanTiles in vrdx_api.cpp; checked by tests/native/layout_check.cpp).
 // N <= 2^30 - 4 (the reference's uint32 byte-size math wraps above that, :105-115) keeps every
 // prefix inside 30 bits.
 //
-// The two tile tickets (one per pass parity) sit 512 bytes behind the second status region, in a
-// cache line of their own: every workgroup of a pass hits its ticket with a device-scope atomic, and
-// anything else in that 128-byte line becomes slow to READ meanwhile -- with the tickets in the
-// padding at [4, 12) the line was shared with the first 28 counts of the global histogram, and every
-// pass that read them took 3 us longer (measured: 30.0 vs 27.0 us per pass at N = 2^23).  They are
+// The two tile tickets (one per pass parity) have a 128-byte line to themselves: every workgroup of a pass hits
+// its ticket with a device-scope atomic, and anything else in that line becomes slow to READ meanwhile -- with
+// the tickets in the padding at [4, 12) the line was shared with the first 28 counts of the global histogram,
+// and every pass that read them took 3 us longer (measured: 30.0 vs 27.0 us per pass at N = 2^23).  They are
 // outside the cleared prefix; the histogram kernel zeroes them.
 #ifndef VRDX_LAYOUT_H
 #define VRDX_LAYOUT_H
@@ -87,7 +97,10 @@ struct StorageLayout {
   uint64_t keyValueSize;     // total storage, key-value
 };
 
-static inline StorageLayout MakeLayout(uint32_t maxElementCount, uint32_t align, uint32_t tileKeys) {
+// tiles: status rows are sized for this many tiles (PlanTiles); storageAddress: the absolute address of the storage
+// (buffer + storageOffset) -- only its low 7 bits matter; the sizes do not depend on it.
+static inline StorageLayout MakeLayout(uint32_t maxElementCount, uint32_t align, uint64_t tiles,
+                                       uint64_t storageAddress = 0) {
   StorageLayout l;
   const uint64_t elementCountSize = Align((uint32_t)sizeof(uint32_t), align);
   const uint64_t histogramSize = HistogramSize(maxElementCount, align);
@@ -95,18 +108,72 @@ static inline StorageLayout MakeLayout(uint32_t maxElementCount, uint32_t align,
   l.countOffset = VRDX_OFF_COUNT;
   l.failureOffset = VRDX_OFF_FAILURE;
   l.histogramOffset = elementCountSize;
-  l.statusOffset = l.histogramOffset + VRDX_PASSES * VRDX_RADIX * sizeof(uint32_t);
-  const uint64_t tiles = ((uint64_t)maxElementCount + tileKeys - 1) / tileKeys;
+  const uint64_t tableEnd = l.histogramOffset + VRDX_PASSES * VRDX_RADIX * sizeof(uint32_t);
+  l.statusOffset = tableEnd + ((0 - (storageAddress + tableEnd)) & 127u);
   l.statusRows = tiles > 0 ? tiles - 1 : 0;
   // count + failure + global histogram + status region 0
   l.clearBytes = l.statusOffset + l.statusRows * VRDX_RADIX * sizeof(uint32_t);
-  // 2 * rows KiB <= P - 1 KiB for every tile >= 8192 keys: at least 1 KiB is free behind region 1
-  l.ticketOffset = l.statusOffset + 2 * l.statusRows * VRDX_RADIX * sizeof(uint32_t) + 512;
-  l.inoutOffset = l.histogramOffset + histogramSize;
-  l.valuesOffset = l.inoutOffset + Align((uint32_t)inoutSize, align);
-  l.keysOnlySize = l.inoutOffset + inoutSize;
-  l.keyValueSize = l.valuesOffset + inoutSize;
+  l.ticketOffset = l.statusOffset + 2 * l.statusRows * VRDX_RADIX * sizeof(uint32_t);
+  l.inoutOffset = l.ticketOffset + 128;
+  l.valuesOffset = l.inoutOffset + (((uint64_t)maxElementCount * sizeof(uint32_t) + 127u) & ~(uint64_t)127u);
+  // the reference's totals (what the caller allocates)
+  const uint64_t refInoutOffset = l.histogramOffset + histogramSize;
+  l.keysOnlySize = refInoutOffset + inoutSize;
+  l.keyValueSize = refInoutOffset + Align((uint32_t)inoutSize, align) + inoutSize;
   return l;
+}
+
+// Tile plan.  The 1024x32 kernels hold one workgroup per CU, so a sort of T full tiles takes ceil(T / CUs) rounds
+// however full the last round is: 257 tiles cost two rounds, and so do 512.  Two remedies, both through the kernels'
+// run-time slot counts (OnesweepArgs::slots / fullTiles / tailSlots, SpanOfTile in vrdx_kernels.hip):
+//  * even split (round 3): a sort of no more than one round is cut into `cus` EQUAL tiles (a multiple of four 64-key
+//    slots per wave) instead of tiles of the kernel's capacity;
+//  * tail split (round 4): a longer sort keeps its whole rounds of full tiles, and what is left over -- less than one
+//    round -- is cut into `cus` equal small tiles, so that the last round costs what its keys cost instead of a full
+//    tile's life (profiles/r04_tail_split.txt).
+// Pure integer math, shared with tests/native/layout_check.cpp (every plan's status rows must fit the storage).
+struct TilePlan {
+  uint32_t tiles;      // grid size = status rows + 1
+  uint32_t slots;      // 0: every tile holds the kernel's capacity (the kernels without run-time slot counts)
+  uint32_t fullTiles;  // tiles [0, fullTiles) hold `slots` slots per wave (and sub-tile), the rest tailSlots
+  uint32_t tailSlots;
+};
+
+// threads / keysPerThread / subTiles: the kernel's geometry; splitForms: its forms with run-time slot counts exist;
+// evenSplit: allowed; tailPercent: tail split while the rest is at most this share of a round (0: never).
+static inline TilePlan PlanTiles(uint32_t elementCount, uint32_t cus, uint32_t threads, uint32_t keysPerThread,
+                                 uint32_t subTiles, bool splitForms, bool evenSplit, uint32_t tailPercent) {
+  const uint32_t slotKeys = threads * subTiles;     // keys of a tile per slot
+  const uint32_t capacity = slotKeys * keysPerThread;
+  TilePlan plan;
+  plan.tiles = RoundUp(elementCount, capacity);
+  plan.slots = 0;
+  plan.fullTiles = ~0u;
+  plan.tailSlots = 0;
+  if (elementCount == 0 || !splitForms || cus == 0) return plan;
+  const uint32_t granule = 4u * slotKeys;  // the kernels walk four slots at a time
+  const uint64_t round = (uint64_t)cus * capacity;
+  const uint32_t wholeRounds = (uint32_t)(elementCount / round);
+  if (wholeRounds == 0) {
+    if (!evenSplit) return plan;
+    uint32_t slots = 4u * RoundUp(RoundUp(elementCount, cus), granule);
+    if (slots < 8u) slots = 8u;  // 2 * (tiles - 1) <= P - 1 needs tiles of 8192 keys and more when all tiles are alike
+    if (slots >= keysPerThread) return plan;
+    plan.slots = plan.tailSlots = slots;
+    plan.tiles = RoundUp(elementCount, slots * slotKeys);
+    return plan;
+  }
+  if (tailPercent == 0) return plan;
+  const uint32_t fullTiles = wholeRounds * cus;
+  const uint32_t rest = elementCount - fullTiles * capacity;
+  if (rest == 0 || (uint64_t)rest * 100u > (uint64_t)tailPercent * round) return plan;
+  const uint32_t tailSlots = 4u * RoundUp(RoundUp(rest, cus), granule);
+  if (tailSlots >= keysPerThread) return plan;
+  plan.slots = keysPerThread;
+  plan.fullTiles = fullTiles;
+  plan.tailSlots = tailSlots;
+  plan.tiles = fullTiles + RoundUp(rest, tailSlots * slotKeys);
+  return plan;
 }
 
 }  // namespace vrdx
