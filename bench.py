@@ -128,11 +128,12 @@ def timed_sorts(torch, dist, executor, streams, n, steps, warmup, key_value, dev
 
 
 def stage_profile(torch, sorter, n, key_value, device, repeats=5):
-    """Per-kernel durations from the 15-slot timestamp contract (HIP events on the sort's own stream): returns
-    (histogram_ms, mean onesweep launch ms).  The stamped sort runs right BEHIND another sort of a different array,
-    like every sort of the timed region does: a kernel is charged for the write-back of what the kernel before it
-    has just written (the histogram takes 30 us after an idle gap and 40-44 us behind a
-    sort), and with the stream busy the host's enqueue latency stays out of the stamps."""
+    """Per-kernel event intervals from the 15-slot timestamp contract (HIP events on the sort's own stream): returns
+    (histogram_ms, mean onesweep launch ms) AS STAMPED, i.e. each including one event record (main() subtracts the
+    calibrated cost of that, vrdxHipEventOverheadNs, to get kernel time).  The stamped sort runs right BEHIND another
+    sort of a different array, like every sort of the timed region does: a kernel is charged for the write-back of what
+    the kernel before it has just written (the histogram takes 30 us after an idle gap and
+    40-44 us behind a sort), and with the stream busy the host's enqueue latency stays out of the stamps."""
     import vulkan_radix_sort_amd as vrdx
     stream = torch.cuda.current_stream().cuda_stream
     req = sorter.key_value_storage_requirements(n) if key_value else sorter.storage_requirements(n)
@@ -229,23 +230,21 @@ def latest_pmc_traffic(version):
     return pmc
 
 
-def committed_rocprof_averages():
+def committed_rocprof_averages(version):
     """Per-kernel average durations (us) of the rocprofv3 --kernel-trace --stats run of THIS command committed under
-    profiles/ (the newest rNN_rocprofv3_kernel_stats.csv), so that the event-timed figures of this line can be
-    compared with the profiler's from the JSON alone.  None when no such file is there."""
-    import csv
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_kernel_stats.csv")))
-    if not files:
+    profiles/ (profiles/kernel_stats.json, written by tools/kernel_stats.py --json from the newest
+    rNN_rocprofv3_kernel_stats.csv), so that the event-timed figures of this line can be compared with the profiler's
+    from the JSON alone.  "matches_this_build" says whether that file was taken with these kernel sources and this
+    tile choice; a stale file is still quoted, flagged.  None when no such file is there."""
+    path = os.path.join(ROOT, "profiles", "kernel_stats.json")
+    try:
+        with open(path) as f:
+            stats = json.load(f)
+    except (OSError, ValueError):
         return None
-    rows = {}
-    with open(files[-1]) as f:
-        for row in csv.DictReader(f):
-            if "vrdx::" in row["Name"] and "lds_order_check" not in row["Name"]:
-                name = row["Name"].replace("void vrdx::", "").split("(")[0]
-                rows[name] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3,
-                              "min_us": float(row["MinNs"]) / 1e3, "max_us": float(row["MaxNs"]) / 1e3}
-    return {"file": os.path.relpath(files[-1], ROOT), "kernels": rows}
+    stats["matches_this_build"] = (stats.get("kernel_source_sha256") == kernel_source_digest()
+                                   and stats.get("library") == version)
+    return stats
 
 
 def kernel_source_digest():
@@ -342,8 +341,15 @@ def main():
     wall_keys, steps_keys = timed_sorts(torch, dist, executor, streams, n, args.steps, args.warmup, False, device, distributed)
     wall_kv, steps_kv = timed_sorts(torch, dist, executor, streams, n, args.steps, args.warmup, True, device, distributed)
     del streams
-    hist_ms, sweep_ms = stage_profile(torch, sorter, n, False, device)
-    hist_kv_ms, sweep_kv_ms = stage_profile(torch, sorter, n, True, device)
+    hist_stamped_ms, sweep_stamped_ms = stage_profile(torch, sorter, n, False, device)
+    hist_kv_stamped_ms, sweep_kv_stamped_ms = stage_profile(torch, sorter, n, True, device)
+    # ONE definition of a launch duration on this line: the event interval around the kernel minus what a pair of event
+    # records adds to a kernel of known duration on this stream (vrdxHipEventOverheadNs: a kernel that times itself
+    # with the device's wall clock, bracketed the same way, median of eight) = kernel time, which is what rocprofv3
+    # reports for the same launches (roofline.rocprof).  The raw intervals stay beside it as stamped_launch_ms.
+    overhead_ms = vrdx.event_overhead_ns(torch.cuda.current_stream().cuda_stream) / 1e6
+    hist_ms, sweep_ms = hist_stamped_ms - overhead_ms, sweep_stamped_ms - overhead_ms
+    hist_kv_ms, sweep_kv_ms = hist_kv_stamped_ms - overhead_ms, sweep_kv_stamped_ms - overhead_ms
     # end-of-batch record of every rank (the batched variant's only collective; 24 bytes per rank)
     records = batch.gather(0, int(wall_kv * 1e9), (args.warmup + 2 * args.steps) * n)
 
@@ -366,19 +372,25 @@ def main():
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
         "traffic": (pmc or {}).get("onesweep_keys_bytes_per_launch"),
         "algorithmic_bytes_per_launch": sweep_bytes, "avg_launch_ms": sweep_ms,
-        "histogram_kernel": {"avg_launch_ms": hist_ms, "achieved": 4.0 * n / (hist_ms * 1e-3) / 1e9,
+        "stamped_launch_ms": sweep_stamped_ms, "event_overhead_ms": overhead_ms,
+        "launch_time_source": "HIP events on the sort's stream (15-slot timestamp contract) minus the calibrated "
+                              "event overhead (vrdxHipEventOverheadNs)",
+        "histogram_kernel": {"avg_launch_ms": hist_ms, "stamped_launch_ms": hist_stamped_ms,
+                             "achieved": 4.0 * n / (hist_ms * 1e-3) / 1e9,
+                             "frac": 4.0 * n / (hist_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                              "algorithmic_bytes_per_launch": 4.0 * n},
         "whole_sort": {"algorithmic_bytes": KEYS_BYTES_PER_ITEM * n,
                        "achieved": KEYS_BYTES_PER_ITEM * n / (med_keys_ms * 1e-3) / 1e9,
                        "frac": KEYS_BYTES_PER_ITEM * n / (med_keys_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
         "key_value": {"kernel": kernel_name(version, "key-value"), "avg_launch_ms": sweep_kv_ms,
+                      "stamped_launch_ms": sweep_kv_stamped_ms,
                       "achieved": 16.0 * n / (sweep_kv_ms * 1e-3) / 1e9,
                       "frac": 16.0 * n / (sweep_kv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                       "whole_sort_achieved": KV_BYTES_PER_ITEM * n / (med_kv_ms * 1e-3) / 1e9,
                       "whole_sort_frac": KV_BYTES_PER_ITEM * n / (med_kv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
     }
 
-    rocprof = committed_rocprof_averages()
+    rocprof = committed_rocprof_averages(version)
     if rocprof:
         roofline["rocprof"] = rocprof
     # counter-measured HBM bytes of the same kernels (profiles/pmc_traffic.json, only while its stamp matches this

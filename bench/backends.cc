@@ -61,7 +61,7 @@ class CpuBenchmark : public BenchmarkBase {
 
 class HipBenchmark : public BenchmarkBase {
  public:
-  HipBenchmark() {
+  explicit HipBenchmark(bool graph) : graph_(graph) {
     VrdxSorterCreateInfo info = {};
     const VkResult r = vrdxCreateSorter(&info, &sorter_);
     if (r != VK_SUCCESS) {
@@ -75,6 +75,7 @@ class HipBenchmark : public BenchmarkBase {
   }
   ~HipBenchmark() override {
     (void)hipStreamSynchronize(stream_);
+    DropGraph();
     if (keys_) (void)hipFree(keys_);
     if (storage_) (void)hipFree(storage_);
     vrdxHipDestroyQueryPool(pool_);
@@ -83,7 +84,9 @@ class HipBenchmark : public BenchmarkBase {
     (void)hipEventDestroy(end_);
     (void)hipStreamDestroy(stream_);
   }
-  std::string LibraryVersion() const override { return vrdxHipVersionString(); }
+  std::string LibraryVersion() const override {
+    return std::string(vrdxHipVersionString()) + (graph_ ? " [hipGraph replay]" : "");
+  }
   bool Healthy() override { return vrdxHipReadSorterStatus(sorter_, (VkCommandBuffer)stream_) == 0; }
 
   Results Sort(const std::vector<uint32_t>& keys) override {
@@ -118,6 +121,7 @@ class HipBenchmark : public BenchmarkBase {
   static uint32_t Align(uint32_t x) { return (x + 15u) / 16u * 16u; }
 
   void Reserve(size_t keysBytes, size_t storageBytes) {
+    if (keysBytes > keysCap_ || storageBytes > storageCap_) DropGraph();  // the captured sort holds the old addresses
     if (keysBytes > keysCap_) {
       if (keys_) BENCH_HIP_OK(hipFree(keys_));
       BENCH_HIP_OK(hipMalloc(reinterpret_cast<void**>(&keys_), keysBytes));
@@ -133,12 +137,33 @@ class HipBenchmark : public BenchmarkBase {
   // The timed sort carries no query pool: total_time is two events around the enqueue (the 15
   // hipEventRecords of the timestamp contract cost ~50 us per sort).  The per-stage split comes
   // from a second, untimed sort (of the already sorted buffer) with the timestamps active.
+  void DropGraph() {
+    if (exec_) (void)hipGraphExecDestroy(exec_);
+    exec_ = nullptr;
+    graphN_ = 0;
+  }
+
   template <typename Record>
   Results Run(uint32_t n, uint32_t inout, bool keyValue, Record record) {
+    if (graph_ && (exec_ == nullptr || graphN_ != n || graphKeyValue_ != keyValue)) {
+      // record once: vrdxCmdSort* into a capturing stream == gpuSort() into a command buffer
+      DropGraph();
+      hipGraph_t graph = nullptr;
+      BENCH_HIP_OK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+      record(VK_NULL_HANDLE);
+      BENCH_HIP_OK(hipStreamEndCapture(stream_, &graph));
+      BENCH_HIP_OK(hipGraphInstantiate(&exec_, graph, nullptr, nullptr, 0));
+      BENCH_HIP_OK(hipGraphDestroy(graph));
+      graphN_ = n;
+      graphKeyValue_ = keyValue;
+    }
     BENCH_HIP_OK(hipDeviceSynchronize());
     const auto cpuStart = std::chrono::steady_clock::now();
     BENCH_HIP_OK(hipEventRecord(start_, stream_));
-    record(VK_NULL_HANDLE);
+    if (graph_)
+      BENCH_HIP_OK(hipGraphLaunch(exec_, stream_));  // submit many
+    else
+      record(VK_NULL_HANDLE);
     BENCH_HIP_OK(hipEventRecord(end_, stream_));
     BENCH_HIP_OK(hipStreamSynchronize(stream_));
     const auto cpuEnd = std::chrono::steady_clock::now();
@@ -177,13 +202,17 @@ class HipBenchmark : public BenchmarkBase {
   uint8_t* keys_ = nullptr;
   uint8_t* storage_ = nullptr;
   size_t keysCap_ = 0, storageCap_ = 0;
+  const bool graph_;
+  hipGraphExec_t exec_ = nullptr;  // the captured sort of (graphN_, graphKeyValue_) on keys_ / storage_
+  uint32_t graphN_ = 0;
+  bool graphKeyValue_ = false;
 };
 
 }  // namespace
 
-std::unique_ptr<BenchmarkBase> CreateBenchmark(const std::string& type) {
+std::unique_ptr<BenchmarkBase> CreateBenchmark(const std::string& type, bool graph) {
   if (type == "cpu") return std::make_unique<CpuBenchmark>();
-  if (type == "hip") return std::make_unique<HipBenchmark>();
+  if (type == "hip") return std::make_unique<HipBenchmark>(graph);
   if (type == "rocprim") return CreateRocprimBenchmark();
   return nullptr;
 }

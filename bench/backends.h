@@ -58,7 +58,10 @@ class DataGenerator {
 
 // "hip" (libvrdx_hip.so through the C-ABI), "cpu" (std::sort / std::stable_sort), and "rocprim"
 // when the driver was built with the comparator (bench/rocprim_backend.hip).
-std::unique_ptr<BenchmarkBase> CreateBenchmark(const std::string& type);
+// graph (hip only): every sort is captured ONCE per (N, mode) into a hipGraph and the timed runs replay it -- the
+// reference's record-once / submit-many model (a command buffer is recorded once and submitted per sort,
+// /root/reference/bench/vulkan_benchmark.cc:292-302): one host call per sort instead of seven or eight enqueues.
+std::unique_ptr<BenchmarkBase> CreateBenchmark(const std::string& type, bool graph = false);
 std::unique_ptr<BenchmarkBase> CreateRocprimBenchmark();  // nullptr when not compiled in
 
 // bench hip --devices G: returns the process exit code (batched.cc).

@@ -2,12 +2,14 @@
 // (/root/reference/bench/bench.cc:15-20,41-112,116-207) so that results are directly comparable with
 // the reference's README table and its tools/plot.py:
 //
-//   bench <type> [-o results.csv] [--no-verify] [--points K]
+//   bench <type> [-o results.csv] [--no-verify] [--points K] [--graph]
 //     <type>      hip | cpu | rocprim            (reference: vulkan | cpu | cuda | fuchsia)
 //     -o          output CSV (default results.csv)
 //     --no-verify skip the one-shot correctness check against the cpu backend at the first point
 //     --points K  number of sweep points between N = 2^18 and 2^25 (default 128, like the reference)
 //     --min-log2n A / --max-log2n B   other sweep ends (the reference hard-codes 18 and 25)
+//     --graph     hip: capture every sort once per (N, mode) into a hipGraph and time its replay (the reference's
+//                 record-once / submit-many model, bench/vulkan_benchmark.cc:292-302); cpu_ms is then one host call
 //   bench hip --devices G [--arrays A] [--log2n L]
 //     the batched many-arrays variant: A independent key+value arrays of 2^L elements, array i on
 //     GPU i mod G, one VrdxSorter + stream + storage per GPU, all enqueued from this one host thread;
@@ -122,7 +124,7 @@ Line Measure(BenchmarkBase& bench, uint32_t n, const char* sort, DataGenerator& 
 
 int main(int argc, char** argv) {
   std::string type, output = "results.csv";
-  bool verify = true;
+  bool verify = true, graph = false;
   int points = 128;  // bench/bench.cc:19 kNCount
   int devices = 0, arrays = 8, batchLog2n = 25;
   for (int i = 1; i < argc; ++i) {
@@ -131,6 +133,8 @@ int main(int argc, char** argv) {
       if (++i < argc) output = argv[i];
     } else if (a == "--no-verify") {
       verify = false;
+    } else if (a == "--graph") {
+      graph = true;
     } else if (a == "--points") {
       if (++i < argc) points = std::max(2, std::atoi(argv[i]));
     } else if (a == "--min-log2n") {
@@ -151,7 +155,7 @@ int main(int argc, char** argv) {
     }
   }
   if (type.empty()) {
-    std::cout << "usage: bench <hip|cpu|rocprim> [-o results.csv] [--no-verify] [--points K] [--min-log2n A] [--max-log2n B]\n"
+    std::cout << "usage: bench <hip|cpu|rocprim> [-o results.csv] [--no-verify] [--points K] [--min-log2n A] [--max-log2n B] [--graph]\n"
                  "       bench hip --devices G [--arrays A] [--log2n L] [--no-verify]   (batched: A key+value arrays of 2^L over G GPUs)"
               << std::endl;
     return 0;
@@ -165,7 +169,11 @@ int main(int argc, char** argv) {
     return RunBatched(devices, arrays, batchLog2n, verify);
   }
 
-  std::unique_ptr<BenchmarkBase> bench = CreateBenchmark(type);
+  if (graph && type != "hip") {
+    std::cerr << "--graph needs the hip backend" << std::endl;
+    return 1;
+  }
+  std::unique_ptr<BenchmarkBase> bench = CreateBenchmark(type, graph);
   if (!bench) {
     std::cerr << "unknown or unavailable backend: " << type << std::endl;
     return 1;

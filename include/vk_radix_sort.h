@@ -195,6 +195,25 @@ uint32_t vrdxHipReadStatus(VkCommandBuffer commandBuffer, VkBuffer storageBuffer
  * void, so this is where such an error surfaces.  Synchronises the given stream (which must belong to
  * the sorter's device and be ordered after the sorts in question). */
 uint32_t vrdxHipReadSorterStatus(VrdxSorter sorter, VkCommandBuffer commandBuffer);
+/* Bits of that word (and of the one line vrdxDestroySorter prints on stderr when a sorter is destroyed with any of
+ * them never read -- the vrdxCmdSort* entry points return void like the reference's, so nothing fails silently): */
+#define VRDX_HIP_STATUS_LOOKBACK_GAVE_UP 0x00000001u /* a bounded look-back spin expired: that sort's result is unspecified */
+#define VRDX_HIP_STATUS_RANK_ORDER       0x00000002u /* the periodic repeat of the LDS lane-order check failed: vrdxHipRecheck */
+#define VRDX_HIP_STATUS_ENQUEUE_REFUSED  0x80000000u /* the HIP runtime refused a fill, copy or launch of a sort */
+
+/* Repeats, synchronously (~1 ms), the device check vrdxCreateSorter ran for the one-atomic ranking (LDS returning atomics
+ * served in lane order: measured on every MI355X so far, not promised by the ISA manual) and switches the sorter to the
+ * ballot ranking for the sorts recorded from then on if it fails (one line on stderr).  A small stream-ordered repeat
+ * is recorded by the library itself behind every 65536th sort (VRDX_HIP_STATUS_RANK_ORDER); call this after a driver or
+ * firmware update under a long-lived process, or whenever that bit shows up.  Not thread-safe against sorts being
+ * recorded with the same sorter at the same time only in the sense that those may still use the old ranking. */
+VkResult vrdxHipRecheck(VrdxSorter sorter);
+
+/* What a pair of hipEventRecords adds to the kernel between them on this stream, in nanoseconds: the median over eight
+ * runs of (event interval - the time a spinning kernel demonstrably ran by the device's own wall clock).  Slot
+ * differences of the 15-slot timestamp contract include this much on top of the kernel's duration; bench.py subtracts
+ * it to report kernel time (synchronises the stream; ~0.5 ms).  ~0 on failure is not assumed: returns UINT64_MAX then. */
+uint64_t vrdxHipEventOverheadNs(VkCommandBuffer commandBuffer);
 
 /* Library build info: "vrdx-hip <version> gfx950 tiles at 2^25: keys=<threads>x<keys per thread>[x<sub-tiles>]
  * key-value=... (size-adaptive | forced)". */

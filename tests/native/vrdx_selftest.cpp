@@ -446,8 +446,10 @@ void Bench(Harness& h, const std::vector<int>& logs) {
 // Timing-only size sweep for tile-geometry break points: N = 2^(lo + i*(hi-lo)/(points-1)), one
 // random key/value set generated once (each run re-uploads the first N), median of 7 event-bracketed
 // sorts without a query pool.
-void Sweep(Harness& h, double lo, double hi, int points, bool kv) {
-  const uint32_t nMax = (uint32_t)std::llround(std::pow(2.0, hi));
+// linear = true: N = lo + i * (hi - lo) / (points - 1) element counts (the reference's sweep is linear: bench/bench.cc:17-20);
+// otherwise lo and hi are log2 N.
+void Sweep(Harness& h, double lo, double hi, int points, bool kv, bool linear = false) {
+  const uint32_t nMax = linear ? (uint32_t)hi : (uint32_t)std::llround(std::pow(2.0, hi));
   std::vector<uint32_t> v;
   auto k = Mt(nMax, 7, 32, &v);
   VrdxSorterStorageRequirements req;
@@ -460,7 +462,7 @@ void Sweep(Harness& h, double lo, double hi, int points, bool kv) {
   std::printf("%-10s %-5s %10s %12s\n", "n", "sort", "gpu_ms", "GItems/s");
   for (int i = 0; i < points; ++i) {
     const double lg = points > 1 ? lo + (hi - lo) * i / (points - 1) : lo;
-    const uint32_t n = (uint32_t)std::llround(std::pow(2.0, lg));
+    const uint32_t n = linear ? (uint32_t)std::llround(lg) : (uint32_t)std::llround(std::pow(2.0, lg));
     const uint32_t inout = Align16(n * 4u);
     std::vector<uint64_t> t;
     for (int runIdx = 0; runIdx < 8; ++runIdx) {
@@ -711,9 +713,9 @@ int main(int argc, char** argv) {
     vrdxDestroySorter(h.sorter);
     return 0;
   }
-  if (what == "sweep") {  // sweep <lo log2> <hi log2> <points> [keys|kv]
+  if (what == "sweep" || what == "lsweep") {  // sweep <lo log2> <hi log2> <points> [keys|kv]; lsweep <lo n> <hi n> <points> [keys|kv]
     Sweep(h, argc > 2 ? std::atof(argv[2]) : 22.0, argc > 3 ? std::atof(argv[3]) : 26.0, argc > 4 ? std::atoi(argv[4]) : 17,
-          argc > 5 && std::string(argv[5]) == "kv");
+          argc > 5 && std::string(argv[5]) == "kv", what == "lsweep");
     return 0;
   }
   if (what == "passes") {  // passes <log2n> [keys|kv] [runs]

@@ -2,7 +2,9 @@
 ran on AND the sorter's own sticky word; the next sort recorded on that storage clears the former, only
 vrdxHipReadSorterStatus clears the latter.  A real give-up needs 2^18 fruitless trips, so the TEST BUILD of the
 library (make -C vulkan_radix_sort_amd/csrc testing, -DVRDX_TESTING) takes the limit from VRDX_TEST_SPIN_LIMIT: with 0,
-the first trip that has to wait gives up.  Run in a process of its own by tests/test_sort_gpu.py."""
+the first trip that has to wait gives up, and tile 0 of every pass holds its inclusive prefix back for ~0.3 ms
+(TestDelayFirstTile in vrdx_kernels.hip), so that tile 1 is certain to wait: ONE sort suffices, deterministically.
+Run in a process of its own by tests/test_sort_gpu.py."""
 import os
 import sys
 
@@ -21,14 +23,10 @@ n = 1 << 24
 rng = np.random.default_rng(11)
 storage = torch.empty(s.storage_requirements(n).size, dtype=torch.uint8, device="cuda")
 assert s.read_sorter_status(stream) == 0
-word = 0
-for attempt in range(4):   # 512 tiles x 4 passes: some tile has to wait for a predecessor in practice every time
-    keys = torch.from_numpy(rng.integers(0, 2**32, n, dtype=np.uint32).view(np.int32)).cuda()
-    s.cmd_sort(stream, n, keys.data_ptr(), 0, storage.data_ptr(), 0)
-    torch.cuda.synchronize()
-    word = s.read_status(stream, storage.data_ptr(), 0)
-    if word != 0:
-        break
+keys = torch.from_numpy(rng.integers(0, 2**32, n, dtype=np.uint32).view(np.int32)).cuda()
+s.cmd_sort(stream, n, keys.data_ptr(), 0, storage.data_ptr(), 0)   # tile 1 waits for the delayed tile 0 and gives up
+torch.cuda.synchronize()
+word = s.read_status(stream, storage.data_ptr(), 0)
 # a small sort on the SAME storage: single-workgroup path, no look-back, clears the storage's failure word
 small = torch.from_numpy(rng.integers(0, 2**32, 1000, dtype=np.uint32).view(np.int32)).cuda()
 s.cmd_sort(stream, 1000, small.data_ptr(), 0, storage.data_ptr(), 0)

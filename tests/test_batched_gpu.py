@@ -62,6 +62,40 @@ def test_hip_shard_executor_sorts_mixed_arrays_through_one_storage(oracle):
     ex.close()
 
 
+def test_hip_shard_executor_orders_sorts_enqueued_on_different_streams(oracle):
+    """All sorts of an executor share ONE storage buffer (histogram, status rows, tickets, scratch arrays), so two
+    of them must never be in flight at once.  A caller that switches torch's current stream between two enqueue()
+    calls gets a device-side dependency between the streams (wait_stream), the storage is recorded on every stream
+    that uses it, and a buffer that had to grow stays alive until finish(): several large sorts alternating between
+    two streams, the later ones needing a bigger storage, with no host synchronisation in between -- every result
+    bit-exact, sorter status 0.  (Without the ordering these sorts overlap on the GPU and clobber each other's
+    status rows and scratch arrays.)"""
+    import torch
+    from vulkan_radix_sort_amd.batched import HipShardExecutor
+    device = torch.cuda.current_device()
+    ex = HipShardExecutor(device)
+    streams = [torch.cuda.Stream(device), torch.cuda.Stream(device)]
+    sizes = [(1 << 22) + 3, (1 << 22) + 3, 3_000_001, (1 << 23) + 77, 1 << 22, (1 << 23) + 77]   # the fourth grows the storage
+    arrays, expected = [], []
+    for i, n in enumerate(sizes):
+        k, v = oracle.generate(300 + i, n, 32)
+        dk = torch.from_numpy(k.view(np.int32).copy()).cuda(device)
+        dv = torch.from_numpy(v.view(np.int32).copy()).cuda(device) if i % 2 == 0 else None
+        arrays.append((dk, dv))
+        expected.append(oracle.sort(k, v if dv is not None else None))
+    torch.cuda.synchronize()
+    for i, pair in enumerate(arrays):
+        with torch.cuda.stream(streams[i % 2]):
+            ex.enqueue([pair])
+    assert ex.finish() == 0
+    torch.cuda.synchronize()
+    for (dk, dv), (ek, ev, _) in zip(arrays, expected):
+        assert np.array_equal(dk.cpu().numpy().view(np.uint32), ek)
+        if dv is not None:
+            assert np.array_equal(dv.cpu().numpy().view(np.uint32), ev)
+    ex.close()
+
+
 def test_one_gpus_share_of_the_batched_config_at_full_size(oracle, golden):
     """BASELINE.json configs[4] at G = 1: the eight independent N = 2^25 key+value arrays (seeds 1..8, the reference's
     generator) that the 8-GPU run shards one per GPU, sorted here by ONE GPU's executor through its one storage
@@ -201,3 +235,19 @@ def test_bench_driver_backends(tmp_path, backend, points, lo, hi):
     assert int(rows[0][1]) == 1 << lo and int(rows[-1][1]) == 1 << hi
     if backend == "hip":
         assert out.read_text().startswith("# version: vrdx-hip")
+
+
+def test_bench_driver_graph_replay_mode(tmp_path):
+    """bench hip --graph: every sort is captured once per (N, mode) into a hipGraph and the timed runs replay it (the
+    reference's record-once / submit-many model, bench/vulkan_benchmark.cc:292-302).  The one-shot correctness check
+    runs THROUGH the replayed graphs (keys-only, then key+value indirect: the device-side count is read on replay);
+    same CSV; the version line says which mode produced it."""
+    out = tmp_path / "graph.csv"
+    r = subprocess.run([_bench_exe(), "hip", "--graph", "--points", "3", "--min-log2n", "18", "--max-log2n", "22", "-o", str(out)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Correctness check passed" in r.stdout
+    text = out.read_text()
+    assert text.startswith("# version: vrdx-hip") and "[hipGraph replay]" in text.splitlines()[0]
+    rows = [l.split(",") for l in text.splitlines()[2:]]
+    assert len(rows) == 6 and all(float(r_[3]) > 0 and float(r_[4]) > 0 for r_ in rows)

@@ -12,6 +12,12 @@ export TMPDIR=/tmp
 timeout 900 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 # 2. kernel trace + stats of the same command
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kernel_stats -o stats -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err
+S=$(find $OUT/kernel_stats -name '*kernel_stats.csv' | head -1)
+cp "$S" $OUT/rocprofv3_kernel_stats.csv 2>/dev/null
+python3 tools/kernel_stats.py "$S" --json $OUT/kernel_stats.json > $OUT/kernel_stats.txt 2>&1
+# the same for the passes of a sort one at a time (histogram + 4 passes per sort, by pass index)
+T=$(find $OUT/kernel_stats -name '*kernel_trace.csv' | head -1)
+python3 tools/pass_parity.py "$T" 0 > $OUT/pass_parity_under_bench.txt 2>&1
 # 3. PMC passes (separate runs, counters only + kernel trace)
 (cd tools/probes && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 pmc_calibrate.hip -I$ROOT/include -L$ROOT/vulkan_radix_sort_amd -lvrdx_hip \
     -Wl,-rpath,$ROOT/vulkan_radix_sort_amd -o /tmp/pmc_calibrate) 2> $OUT/pmc_build.err

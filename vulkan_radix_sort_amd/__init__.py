@@ -18,6 +18,7 @@ from .api import (  # noqa: F401
     load_library,
     EXPORTED_SYMBOLS,
     version_string,
+    event_overhead_ns,
 )
 
 __all__ = [
@@ -30,4 +31,5 @@ __all__ = [
     "load_library",
     "EXPORTED_SYMBOLS",
     "version_string",
+    "event_overhead_ns",
 ]

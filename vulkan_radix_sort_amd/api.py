@@ -50,8 +50,15 @@ EXPORTED_SYMBOLS = (
     "vrdxHipGetQueryPoolResults",
     "vrdxHipReadStatus",
     "vrdxHipReadSorterStatus",
+    "vrdxHipRecheck",
+    "vrdxHipEventOverheadNs",
     "vrdxHipVersionString",
 )
+
+# bits of vrdxHipReadSorterStatus (include/vk_radix_sort.h)
+STATUS_LOOKBACK_GAVE_UP = 0x00000001
+STATUS_RANK_ORDER = 0x00000002
+STATUS_ENQUEUE_REFUSED = 0x80000000
 
 
 class VrdxError(RuntimeError):
@@ -73,13 +80,18 @@ class VrdxSorterStorageRequirements(ctypes.Structure):
     _fields_ = [("size", ctypes.c_uint64), ("usage", ctypes.c_uint32)]
 
 
+def in_tree_library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvrdx_hip.so")
+
+
 def library_path() -> str:
     """The in-tree libvrdx_hip.so.  VRDX_LIBRARY names another BUILD of the same library instead (the -DVRDX_TESTING
-    build of two tests, a tuning variant of tools/); it is never a fallback: a missing file is an error either way."""
+    build of two tests, a tuning variant of tools/); it is never a fallback: a missing file is an error either way,
+    and ``load_library`` says on stderr that the override is active and refuses a library of another version."""
     override = os.environ.get("VRDX_LIBRARY")
     if override:
         return os.path.abspath(override)
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvrdx_hip.so")
+    return in_tree_library_path()
 
 
 _LIB: Optional[ctypes.CDLL] = None
@@ -96,6 +108,22 @@ def load_library() -> ctypes.CDLL:
             f"{path} is missing: build it with `make -C vulkan_radix_sort_amd/csrc` "
             "(or __graft_entry__.build()).  There is no CPU fallback.")
     lib = ctypes.CDLL(path)
+    if path != in_tree_library_path():
+        # A stale VRDX_LIBRARY (left behind by a tuning script, or the test build with its injection hooks) silently
+        # changes what production code runs: say so, and insist on the same version and ABI.
+        import sys
+        missing = [name for name in EXPORTED_SYMBOLS if not hasattr(lib, name)]
+        if missing:
+            raise ImportError(f"VRDX_LIBRARY={path} does not export {', '.join(missing)}: not a build of this library")
+        lib.vrdxHipVersionString.restype = ctypes.c_char_p
+        theirs = lib.vrdxHipVersionString().decode()
+        if os.path.exists(in_tree_library_path()):
+            own = ctypes.CDLL(in_tree_library_path())
+            own.vrdxHipVersionString.restype = ctypes.c_char_p
+            ours = own.vrdxHipVersionString().decode()
+            if theirs.split()[:2] != ours.split()[:2]:
+                raise ImportError(f"VRDX_LIBRARY={path} is '{theirs}', the in-tree library is '{ours}': version mismatch")
+        print(f"vulkan_radix_sort_amd: VRDX_LIBRARY override active, loaded {path} ({theirs})", file=sys.stderr)
     vp, u32, u64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64
     lib.vrdxCreateSorter.restype = ctypes.c_int32
     lib.vrdxCreateSorter.argtypes = [ctypes.POINTER(VrdxSorterCreateInfo), ctypes.POINTER(vp)]
@@ -123,6 +151,10 @@ def load_library() -> ctypes.CDLL:
     lib.vrdxHipReadStatus.argtypes = [vp, vp, u64]
     lib.vrdxHipReadSorterStatus.restype = u32
     lib.vrdxHipReadSorterStatus.argtypes = [vp, vp]
+    lib.vrdxHipRecheck.restype = ctypes.c_int32
+    lib.vrdxHipRecheck.argtypes = [vp]
+    lib.vrdxHipEventOverheadNs.restype = u64
+    lib.vrdxHipEventOverheadNs.argtypes = [vp]
     lib.vrdxHipVersionString.restype = ctypes.c_char_p
     lib.vrdxHipVersionString.argtypes = []
     _LIB = lib
@@ -131,6 +163,15 @@ def load_library() -> ctypes.CDLL:
 
 def version_string() -> str:
     return load_library().vrdxHipVersionString().decode()
+
+
+def event_overhead_ns(command_buffer) -> int:
+    """``vrdxHipEventOverheadNs``: what a pair of event records adds to the kernel between them on this stream (ns),
+    measured against a kernel that times itself with the device's wall clock.  Raises if the calibration failed."""
+    ns = int(load_library().vrdxHipEventOverheadNs(_handle(command_buffer)))
+    if ns == 0xFFFFFFFFFFFFFFFF:
+        raise VrdxError("vrdxHipEventOverheadNs", -4)
+    return ns
 
 
 def _handle(x) -> Optional[int]:
@@ -251,6 +292,14 @@ class Sorter:
         """OR of the failure bits of every sort recorded with this sorter since the previous call,
         whatever storage they used (``vrdxHipReadSorterStatus``); synchronises the stream."""
         return int(self._lib.vrdxHipReadSorterStatus(self.handle, _handle(command_buffer)))
+
+
+    def recheck(self) -> None:
+        """``vrdxHipRecheck``: repeats the device check behind the one-atomic ranking and falls back to the ballot
+        ranking for later sorts if it fails (synchronous, ~1 ms)."""
+        r = self._lib.vrdxHipRecheck(self.handle)
+        if r != VK_SUCCESS:
+            raise VrdxError("vrdxHipRecheck", r)
 
 
 def _pool(p) -> Optional[int]:

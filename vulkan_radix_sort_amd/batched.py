@@ -41,7 +41,14 @@ class HipShardExecutor:
     executor, i.e. per GPU.  ``enqueue`` never blocks the host -- like the
     ``vrdxCmdSort*`` calls it wraps -- and ``finish`` synchronises once and returns the sorter's sticky
     failure word (``vrdxHipReadSorterStatus``): the OR over EVERY sort enqueued since the last
-    ``finish``, although they all share one storage buffer whose own failure word each of them clears."""
+    ``finish``, although they all share one storage buffer whose own failure word each of them clears.
+
+    All sorts of an executor share ONE storage buffer (histogram, status rows, tickets, scratch arrays), which
+    the reference's contract allows only for sorts that are not in flight at the same time.  A caller that
+    switches torch's current stream between two ``enqueue`` calls would break that, so the executor orders
+    every stream it is handed behind the previous one's work (``wait_stream``: a device-side dependency, the
+    host never blocks) and tells the caching allocator that the storage is in use there (``record_stream``);
+    a storage buffer that had to grow is kept alive until ``finish``."""
 
     def __init__(self, device: Optional[int] = None):
         import torch
@@ -52,12 +59,14 @@ class HipShardExecutor:
         self.device = torch.cuda.current_device() if device is None else int(device)
         self.sorter = Sorter(self.device)
         self._storage = None
+        self._retired = []  # outgrown storage buffers that sorts in flight may still use (dropped by finish())
         self._streams = []  # every stream sorts were enqueued on since the last finish()
+        self._last = None   # the stream of the most recent enqueue
 
     def _storage_for(self, nbytes: int):
         if self._storage is None or self._storage.numel() < nbytes:
-            # (sorts still in flight use the old buffer: stream order keeps it alive long enough,
-            # torch's caching allocator does not hand it out again before they have run)
+            if self._storage is not None:
+                self._retired.append(self._storage)  # sorts in flight (on whatever stream) still use it
             self._storage = self.torch.empty(nbytes, dtype=self.torch.uint8, device=f"cuda:{self.device}")
         return self._storage
 
@@ -75,6 +84,9 @@ class HipShardExecutor:
         stream = current.cuda_stream
         if all(st.cuda_stream != stream for st in self._streams):
             self._streams.append(current)
+        if self._last is not None and self._last.cuda_stream != stream:
+            current.wait_stream(self._last)  # the shared storage: never two sorts in flight at once
+        self._last = current
         need, items = 16, 0
         for keys, values in arrays:
             self._check(keys, "keys")
@@ -87,6 +99,7 @@ class HipShardExecutor:
                    else self.sorter.storage_requirements(n))
             need = max(need, req.size)
         storage = self._storage_for(need)
+        storage.record_stream(current)  # (allocated on another stream, possibly: the allocator must know)
         for keys, values in arrays:
             n = keys.numel()
             if values is None:
@@ -102,9 +115,12 @@ class HipShardExecutor:
         now -- and returns the OR of the failure bits of all of it (0 = ok; ``describe_status`` names the bits)."""
         streams = self._streams or [self.torch.cuda.current_stream(self.device)]
         self._streams = []
+        self._last = None
         for st in streams[:-1]:
             st.synchronize()
-        return self.sorter.read_sorter_status(streams[-1].cuda_stream)
+        status = self.sorter.read_sorter_status(streams[-1].cuda_stream)
+        self._retired = []
+        return status
 
     def __call__(self, arrays: Sequence[tuple]) -> int:
         self.enqueue(arrays)
@@ -115,9 +131,11 @@ class HipShardExecutor:
 
 
 def describe_status(word: int) -> str:
-    """The two independent diagnoses of vrdxHipReadSorterStatus: bit 0 = a look-back gave up on the DEVICE (bounded
-    spin expired, the result of that sort is unspecified); bit 31 = the RUNTIME refused an enqueue of a sort (fill,
-    copy or kernel launch) on the host side, i.e. that sort never ran as recorded."""
+    """The independent diagnoses of vrdxHipReadSorterStatus (include/vk_radix_sort.h, VRDX_HIP_STATUS_*): bit 0 = a
+    look-back gave up on the DEVICE (bounded spin expired, the result of that sort is unspecified); bit 1 = the periodic
+    repeat of the LDS lane-order check failed (the one-atomic ranking rests on it: call ``Sorter.recheck``); bit 31 = the
+    RUNTIME refused an enqueue of a sort (fill, copy or kernel launch) on the host side, i.e. that sort never ran as
+    recorded."""
     if word == 0:
         return "ok"
     if word == 0xFFFFFFFF:
@@ -125,8 +143,12 @@ def describe_status(word: int) -> str:
     parts = []
     if word & 0x80000000:
         parts.append("an enqueue was refused by the HIP runtime (bit 31)")
-    if word & 0x7FFFFFFF:
-        parts.append("a device-side look-back spin expired (0x%x)" % (word & 0x7FFFFFFF))
+    if word & 0x1:
+        parts.append("a device-side look-back spin expired (bit 0)")
+    if word & 0x2:
+        parts.append("LDS atomics were seen out of lane order by the periodic re-check (bit 1)")
+    if word & 0x7FFFFFFC:
+        parts.append("unknown bits 0x%x" % (word & 0x7FFFFFFC))
     return "; ".join(parts)
 
 

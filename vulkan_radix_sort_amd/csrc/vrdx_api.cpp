@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "../../include/vk_radix_sort.h"
 #include "vrdx_kernels.h"
@@ -26,7 +27,12 @@ struct VrdxSorter_T {
   int device = 0;
   int computeUnits = 0;
   // (tile geometry is chosen per sort from the element count, see ConfigIndex)
-  bool atomicRank = false;  // LDS returning atomics proven lane-ordered on this device
+  // LDS returning atomics proven lane-ordered on this device (at creation; vrdxHipRecheck may revise it)
+  std::atomic<bool> atomicRank{false};
+  // sorts recorded on the general path: behind every 65536th one a small, stream-ordered repeat of the lane-order check
+  // is recorded (bit 1 of the sticky word) -- the property is not in the ISA manual, a driver or firmware update under a
+  // long-lived process must not turn into silently unstable sorts
+  mutable std::atomic<uint32_t> sortsRecorded{0};
   // One device word owned by the sorter: kernels OR their failure bit into it and nothing but
   // vrdxHipReadSorterStatus clears it, so a caller that reuses ONE storage buffer for many sorts (each
   // of which clears the storage's own failure word) still learns about a failure in any of them.
@@ -92,28 +98,29 @@ int ForcedConfigIndex() {
 //    (1, 2], just below 4 or 6.
 enum : int { kCfg1024x8 = 0, kCfg1024x16 = 1, kCfg1024x32 = 2, kCfg1024x32x2 = 3 };
 
-int ConfigIndex(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount) {
+int ConfigIndex(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount, bool atomicRank) {
   const int forced = ForcedConfigIndex();
   // (the two-sub-tile kernel is keys-only: a key+value sort under a forced 1024x32x2 takes 1024x32)
-  if (forced >= 0) return forced == kCfg1024x32x2 && (keyValue || !sorter->atomicRank) ? kCfg1024x32 : forced;
+  if (forced >= 0) return forced == kCfg1024x32x2 && (keyValue || !atomicRank) ? kCfg1024x32 : forced;
   const double f = (double)elementCount / ((double)sorter->computeUnits * 32768.0);
   if (keyValue) {
     if (f <= 0.26) return kCfg1024x8;
     if (f <= 0.53) return kCfg1024x16;
     // just past one round of 32768-element tiles, two workgroups of 16384 per CU fill the second round's gap
-    // (1.2-2.6 % at 1.07 <= f <= 1.32, profiles/r03_sweep_by_geometry.txt)
+    // (1.2-2.6 % at 1.07 <= f <= 1.32, profiles/r03_sweep_by_geometry.txt; still so with the tail split of round 4,
+    // profiles/r04_tail_split_kv.txt)
     if (f > 1.0 && f <= 1.35) return kCfg1024x16;
     return kCfg1024x32;
   }
   if (f <= 0.125) return kCfg1024x8;
-  if (f <= 0.5) return kCfg1024x16;   // beyond: even-split 1024x32 tiles (EvenSplitSlots), 7 % faster at f = 0.536
+  if (f <= 0.5) return kCfg1024x16;   // beyond: even-split 1024x32 tiles (PlanTiles), 7 % faster at f = 0.536
   if (f <= 1.0) return kCfg1024x32;
-  // the two-sub-tile kernel holds two sub-tiles' keys in registers: only with the one-atomic ranking
-  const int pair = sorter->atomicRank ? kCfg1024x32x2 : kCfg1024x32;
-  if (f <= 2.0) return pair;           // one round of 65536-key tiles instead of two of 32768
-  if (f <= 3.3) return kCfg1024x32;
-  if (f <= 4.0) return pair;           // two rounds instead of four
-  return kCfg1024x32;
+  // Beyond one round the two-sub-tile kernel (65536 keys per workgroup: half the look-backs per key), whose last,
+  // partial round is cut into small equal tiles (tail split, PlanTiles): with that it is the fastest geometry at every
+  // size from one round up (profiles/r04_tail_split_keys.txt; without it, it lost a whole 65536-key round to the
+  // 1024x32 tiles whenever the tile count passed a multiple of the CU count -- f in (2, 3.3] and beyond 4 in round 3).
+  // It holds two sub-tiles' keys in registers: only with the one-atomic ranking.
+  return atomicRank ? kCfg1024x32x2 : kCfg1024x32;
 }
 
 #ifdef VRDX_TRACE
@@ -159,12 +166,13 @@ int TuningKnob(const char* name) {
 // Mid-size sorts record the hybrid plan (vrdx_kernels.hip, PassPlan) next to the four passes: launch 0 scatters by the
 // keys' highest byte that varies and bucket_sort_kernel finishes every bucket inside one workgroup -- if the DEVICE finds that no bucket
 // exceeds the capacity returned here; otherwise the four passes run as usual and the bucket launch is empty.  The
-// capacity is the smallest of 4096 / 8192 / 16384 (keys-only sorts with the one-atomic ranking: / 32768) that leaves a
-// bucket twice the room of its mean N / 256; the largest one is recorded as long as it leaves 10 % (a bucket sort
-// costs what the bucket's elements cost, whatever the capacity; uniform keys spread by a fraction of a percent at
-// these sizes, and a plan that does not apply costs one empty launch, 3 us, where one that does saves 17-25 %):
-// N <= 7.6 M elements (3.8 M with the ballot ranking).  0 = the plan is not recorded (larger N, a forced tile geometry, VRDX_HYBRID=0).
-uint32_t HybridCapacity(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount) {
+// capacity is the smallest of 4096 / 8192 / 16384 / 32768 (the last one with the one-atomic ranking only) that leaves a
+// bucket twice the room of its mean N / 256; the largest one is recorded as long as it leaves 3 % (a bucket sort
+// costs what the bucket's elements cost, whatever the capacity; uniform keys spread by half a percent at these sizes --
+// mean 31800, sigma 178 at 8.1 M: the capacity is 5 sigma away -- and a plan that does not apply costs one empty
+// launch, 3 us, where one that does saves 17-25 %): N <= 8.1 M elements (4.0 M with the ballot ranking).
+// 0 = the plan is not recorded (larger N, a forced tile geometry, VRDX_HYBRID=0).
+uint32_t HybridCapacity(bool atomicRank, uint32_t elementCount) {
   static const bool enabled = [] {
     const char* env = std::getenv("VRDX_HYBRID");  // "0": always the four-pass plan (testing / measurements)
     return env == nullptr || env[0] != '0';
@@ -176,11 +184,10 @@ uint32_t HybridCapacity(const VrdxSorter_T* sorter, bool keyValue, uint32_t elem
   static const int knobLast = TuningKnob("VRDX_HYBRID_HEADROOM_LAST");
   const uint64_t mean = (elementCount + VRDX_RADIX - 1) / VRDX_RADIX;
   const uint32_t need = (uint32_t)(mean * (uint64_t)(knob > 0 ? knob : 200) / 100u);
-  const uint32_t needLast = (uint32_t)(mean * (uint64_t)(knobLast > 0 ? knobLast : 110) / 100u);
+  const uint32_t needLast = (uint32_t)(mean * (uint64_t)(knobLast > 0 ? knobLast : 103) / 100u);
   // 32768-element buckets: the one-atomic ranking only (the ballot forms of that kernel would spill); key+value stages
   // keys and values through one buffer there (SharedStage in vrdx_kernels.hip)
-  (void)keyValue;
-  const uint32_t largest = sorter->atomicRank ? 32768u : 16384u;
+  const uint32_t largest = atomicRank ? 32768u : 16384u;
   if (need <= 4096u) return 4096u;
   if (need <= 8192u) return 8192u;
   if (need <= 16384u) return 16384u;
@@ -236,20 +243,27 @@ void StampSame(VrdxHipQueryPool* pool, uint32_t slot, uint32_t same) {
 }
 
 // The tile plan of a sort (vrdx_layout.h, PlanTiles): even-split tiles for sorts of one round, tail-split tiles behind
-// the whole rounds of a longer one.  VRDX_EVEN_SPLIT=0 / VRDX_TAIL_SPLIT=0 turn them off, VRDX_TAIL_SPLIT=p limits the
-// tail split to rests of at most p % of a round (measurements).
-bool SplitFormsBuilt(int configIndex, bool keyValue, bool atomicRank) {
-  if (configIndex == kCfg1024x32x2) return !keyValue && atomicRank;
-  return configIndex == kCfg1024x32;
-}
-
-vrdx::TilePlan PlanTiles(const VrdxSorter_T* sorter, int configIndex, bool keyValue, uint32_t elementCount) {
+// the whole rounds of a longer one -- where the kernels' forms with run-time slot counts exist and where they were
+// measured to pay (profiles/r04_tail_split_keys.txt, r04_tail_split_kv.txt; f = size in rounds of CUs x 32768):
+//   keys-only 1024x32x2   even split (-9.5 % at f = 1.07) and tail split at every size (f = 2.06: 0.191 instead of
+//                         0.230 ms; 3.06: 0.261 / 0.272; 4.06: 0.340 / 0.388)
+//   keys-only 1024x32     even split (-3.5 % at f = 0.5); NO tail split (+0 ... +4 %: these tiles are short enough that
+//                         a few of them in a last round cost what 256 small ones cost)
+//   key+value 1024x32     NO even split (its split form fetches the values late, vrdx_kernels.hip: +2 ... +7 % at
+//                         0.55 < f < 1); tail split while the rest is at most half a round (f = 1.06: 0.184 / 0.193 ms,
+//                         2.06: 0.294 / 0.303, 3.06: 0.399 / 0.408, 4.06: 0.524 / 0.532; beyond half a round -1 ... +4 %)
+// VRDX_EVEN_SPLIT=0 / VRDX_TAIL_SPLIT=0 turn them off, VRDX_EVEN_SPLIT=1 / VRDX_TAIL_SPLIT=p (percent of a round) force
+// them wherever the forms exist (measurements).
+vrdx::TilePlan PlanTiles(const VrdxSorter_T* sorter, int configIndex, bool keyValue, uint32_t elementCount, bool atomicRank) {
   static const int evenKnob = TuningKnob("VRDX_EVEN_SPLIT");
   static const int tailKnob = TuningKnob("VRDX_TAIL_SPLIT");
   const vrdx::TileConfig& c = vrdx::kTileConfigs[configIndex];
+  const bool pair = configIndex == kCfg1024x32x2;
+  const bool splitForms = pair ? (!keyValue && atomicRank) : configIndex == kCfg1024x32;
+  const bool evenSplit = evenKnob >= 0 ? evenKnob != 0 : !keyValue;
+  const uint32_t tailPercent = tailKnob >= 0 ? (uint32_t)tailKnob : (pair ? 100u : (keyValue ? 50u : 0u));
   return vrdx::PlanTiles(elementCount, (uint32_t)sorter->computeUnits, (uint32_t)c.threads, (uint32_t)c.keysPerThread,
-                         (uint32_t)c.subTiles, SplitFormsBuilt(configIndex, keyValue, sorter->atomicRank), evenKnob != 0,
-                         tailKnob < 0 ? vrdx::kTailSplitPercent : (uint32_t)tailKnob);
+                         (uint32_t)c.subTiles, splitForms, evenSplit, tailPercent);
 }
 
 // reference: gpuSort, src/vk_radix_sort.h.in:344-507
@@ -277,8 +291,9 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     }
   } deviceScope(sorter->device);
 
-  const int configIndex = ConfigIndex(sorter, keyValue, elementCount);
-  const vrdx::TilePlan tilePlan = PlanTiles(sorter, configIndex, keyValue, elementCount);
+  const bool atomicRank = sorter->atomicRank.load(std::memory_order_relaxed);  // one answer for the whole sort
+  const int configIndex = ConfigIndex(sorter, keyValue, elementCount, atomicRank);
+  const vrdx::TilePlan tilePlan = PlanTiles(sorter, configIndex, keyValue, elementCount, atomicRank);
   uint8_t* const storage = BufferAddress(storageBuffer, storageOffset);
   const vrdx::StorageLayout layout = vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment,
                                                       tilePlan.tiles, (uint64_t)reinterpret_cast<uintptr_t>(storage));
@@ -305,7 +320,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   if (elementCount <= vrdx::kSmallSortMaxElements && ForcedConfigIndex() < 0 && SmallSortEnabled()) {
     for (uint32_t s = 1; s < 14; ++s) StampSame(pool, query + s, query + 0);
     EnqueueCheck(sorter, "small_sort_kernel",
-                 vrdx::LaunchSmallSort(stream, sorter->atomicRank, keys, values, elementCount, countPtr,
+                 vrdx::LaunchSmallSort(stream, atomicRank, keys, values, elementCount, countPtr,
                                        reinterpret_cast<uint32_t*>(storage + layout.failureOffset)));
     Stamp(pool, query + 14, stream);
     return;
@@ -350,7 +365,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   }
 
   const uint32_t tiles = tilePlan.tiles;
-  const uint32_t hybridCap = ForcedConfigIndex() < 0 ? HybridCapacity(sorter, keyValue, elementCount) : 0u;
+  const uint32_t hybridCap = ForcedConfigIndex() < 0 ? HybridCapacity(atomicRank, elementCount) : 0u;
   // Key+value tiles fetch their values early (right after the ranking: they land during the scan and the
   // regroup) -- on the final kernels that is as fast as or faster than fetching them after the
   // look-back at every size (0-8 %, vrdx_selftest sweep with VRDX_KV_EARLY_VALUES=0|1); the late form
@@ -376,7 +391,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
       b.histogramTable = globalHistogram;
       b.hybridCap = hybridCap;
       b.planWord = reinterpret_cast<const uint32_t*>(storage + VRDX_OFF_PLAN);
-      EnqueueCheck(sorter, "bucket_sort_kernel", vrdx::LaunchBucketSort(stream, keyValue, sorter->atomicRank, b));
+      EnqueueCheck(sorter, "bucket_sort_kernel", vrdx::LaunchBucketSort(stream, keyValue, atomicRank, b));
       Stamp(pool, query + 2 + 3 * pass + 0, stream);
     } else {
       StampSame(pool, query + 2 + 3 * pass + 0, query + 2 + 3 * (pass - 1) + 2);
@@ -420,11 +435,17 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     args.trace = TraceBuffer(pass, tiles);
 #endif
     EnqueueCheck(sorter, "onesweep_kernel",
-                 vrdx::LaunchOnesweep(stream, configIndex, tiles, keyValue, sorter->atomicRank, args));
+                 vrdx::LaunchOnesweep(stream, configIndex, tiles, keyValue, atomicRank, args));
 
     Stamp(pool, query + 2 + 3 * pass + 2, stream);  // "downsweep"
   }
   StampSame(pool, query + 14, query + 13);  // end of the sort = end of the last pass
+
+  // Behind every 65536th sort: 8 workgroups repeat the lane-order check of vrdxCreateSorter (~20 us, never blocks; a
+  // mismatch sets VRDX_HIP_STATUS_RANK_ORDER in the sorter's status word, which vrdxHipReadSorterStatus and
+  // vrdxDestroySorter report).
+  if (atomicRank && (sorter->sortsRecorded.fetch_add(1u, std::memory_order_relaxed) & 0xFFFFu) == 0xFFFFu)
+    EnqueueCheck(sorter, "lds_order_check_kernel", vrdx::LaunchLdsOrderRecheck(stream, sorter->stickyStatus));
 }
 
 }  // namespace
@@ -473,10 +494,10 @@ VkResult vrdxCreateSorter(const VrdxSorterCreateInfo* pCreateInfo, VrdxSorter* p
       e = vrdx::LdsOrderCheck(&ordered);
       sorter->atomicRank = ordered;
       if (e == hipSuccess && !ordered) {
-        // Never silent: the ballot form is correct everywhere but 2-3x slower.
+        // Never silent: the ballot form is correct everywhere but 1.2-1.7x slower (profiles/r03_ballot_ranking.txt).
         std::fprintf(stderr,
                      "vrdx-hip: LDS returning atomics are not lane-ordered on device %d: ranking with wave ballots "
-                     "instead (same results, about 2-3x slower)%s\n",
+                     "instead (same results, 1.2-1.7x the time)%s\n",
                      ordinal, mode != nullptr && std::strcmp(mode, "atomic") == 0 ? "; VRDX_RANK=atomic refused" : "");
       }
     }
@@ -497,7 +518,21 @@ void vrdxDestroySorter(VrdxSorter sorter) {
 #ifdef VRDX_TRACE
   DumpTrace();
 #endif
-  if (sorter->stickyStatus != nullptr) (void)hipFree(sorter->stickyStatus);
+  // Last chance to be heard: the vrdxCmdSort* entry points return void like the reference's, so a caller that never
+  // asks vrdxHipReadSorterStatus would not learn that a sort gave up a look-back (result unspecified), that the
+  // lane-order re-check failed or that the runtime refused an enqueue.  One line on stderr, only if something did.
+  if (sorter->stickyStatus != nullptr) {
+    uint32_t word = 0;
+    if (hipMemcpy(&word, sorter->stickyStatus, sizeof(word), hipMemcpyDeviceToHost) != hipSuccess) word = 0;  // (synchronises)
+    if (sorter->enqueueFailed.load(std::memory_order_relaxed) != 0) word |= VRDX_HIP_STATUS_ENQUEUE_REFUSED;
+    if (word != 0)
+      std::fprintf(stderr,
+                   "vrdx-hip: sorter destroyed with unreported failures (status 0x%08x:%s%s%s) -- see vrdxHipReadSorterStatus\n",
+                   word, (word & VRDX_HIP_STATUS_LOOKBACK_GAVE_UP) ? " a look-back spin expired, that sort's result is unspecified;" : "",
+                   (word & VRDX_HIP_STATUS_RANK_ORDER) ? " LDS atomics were seen out of lane order, call vrdxHipRecheck;" : "",
+                   (word & VRDX_HIP_STATUS_ENQUEUE_REFUSED) ? " the HIP runtime refused an enqueue;" : "");
+    (void)hipFree(sorter->stickyStatus);
+  }
   delete sorter;
 }
 
@@ -629,17 +664,73 @@ uint32_t vrdxHipReadSorterStatus(VrdxSorter sorter, VkCommandBuffer commandBuffe
   const hipError_t cleared = hipMemsetAsync(sorter->stickyStatus, 0, sizeof(word), stream);
   // the copy above targets `word` on this stack frame: never return while it may still be in flight
   if (hipStreamSynchronize(stream) != hipSuccess || cleared != hipSuccess) return 0xFFFFFFFFu;
-  if (sorter->enqueueFailed.exchange(0u, std::memory_order_relaxed) != 0) word |= 0x80000000u;
+  if (sorter->enqueueFailed.exchange(0u, std::memory_order_relaxed) != 0) word |= VRDX_HIP_STATUS_ENQUEUE_REFUSED;
   return word;
+}
+
+VkResult vrdxHipRecheck(VrdxSorter sorter) {
+  if (sorter == nullptr) return VK_ERROR_INITIALIZATION_FAILED;
+  const char* mode = std::getenv("VRDX_RANK");
+  if (mode != nullptr && std::strcmp(mode, "ballot") == 0) return VK_SUCCESS;  // nothing rests on the property
+  int previous = 0;
+  (void)hipGetDevice(&previous);
+  if (hipSetDevice(sorter->device) != hipSuccess) return VK_ERROR_DEVICE_LOST;
+  bool ordered = false;
+  const hipError_t e = vrdx::LdsOrderCheck(&ordered);
+  (void)hipSetDevice(previous);
+  if (e != hipSuccess) return VK_ERROR_DEVICE_LOST;
+  const bool was = sorter->atomicRank.exchange(ordered, std::memory_order_relaxed);
+  if (was && !ordered)
+    std::fprintf(stderr,
+                 "vrdx-hip: LDS returning atomics are no longer lane-ordered on device %d: sorts recorded from now on rank "
+                 "with wave ballots (same results, 1.2-1.7x the time); results of earlier sorts may be unstable\n",
+                 sorter->device);
+  return VK_SUCCESS;
+}
+
+uint64_t vrdxHipEventOverheadNs(VkCommandBuffer commandBuffer) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(commandBuffer);
+  int device = 0, clockKhz = 0;
+  unsigned long long* stamps = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  uint64_t result = ~0ull;
+  if (hipGetDevice(&device) != hipSuccess ||
+      hipDeviceGetAttribute(&clockKhz, hipDeviceAttributeWallClockRate, device) != hipSuccess || clockKhz <= 0)
+    return result;
+  if (hipMalloc(reinterpret_cast<void**>(&stamps), 2 * sizeof(unsigned long long)) != hipSuccess) return result;
+  if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+    // a kernel that demonstrably runs 40 us, right behind another one (a busy stream, like the passes of a sort)
+    const uint32_t ticks = (uint32_t)(40ull * (uint64_t)clockKhz / 1000ull);
+    std::vector<uint64_t> extra;
+    for (int run = 0; run < 9; ++run) {
+      unsigned long long host[2] = {0, 0};
+      float ms = 0.0f;
+      if (vrdx::LaunchSpin(stream, stamps, ticks) != hipSuccess || hipEventRecord(e0, stream) != hipSuccess ||
+          vrdx::LaunchSpin(stream, stamps, ticks) != hipSuccess || hipEventRecord(e1, stream) != hipSuccess ||
+          hipStreamSynchronize(stream) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess ||
+          hipMemcpy(host, stamps, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess)
+        break;
+      const double ran = (double)(host[1] - host[0]) * 1.0e6 / (double)clockKhz;  // ns
+      const double between = (double)ms * 1.0e6;
+      if (run > 0) extra.push_back(between > ran ? (uint64_t)(between - ran + 0.5) : 0ull);
+    }
+    if (!extra.empty()) {
+      std::sort(extra.begin(), extra.end());
+      result = extra[extra.size() / 2];
+    }
+  }
+  if (e0 != nullptr) (void)hipEventDestroy(e0);
+  if (e1 != nullptr) (void)hipEventDestroy(e1);
+  (void)hipFree(stamps);
+  return result;
 }
 
 const char* vrdxHipVersionString(void) {
   static char text[160];
   VrdxSorter_T nominal;  // an MI355X: 256 CUs, lane-ordered LDS atomics
   nominal.computeUnits = 256;
-  nominal.atomicRank = true;
-  const vrdx::TileConfig& k = vrdx::kTileConfigs[ConfigIndex(&nominal, false, 1u << 25)];
-  const vrdx::TileConfig& kv = vrdx::kTileConfigs[ConfigIndex(&nominal, true, 1u << 25)];
+  const vrdx::TileConfig& k = vrdx::kTileConfigs[ConfigIndex(&nominal, false, 1u << 25, true)];
+  const vrdx::TileConfig& kv = vrdx::kTileConfigs[ConfigIndex(&nominal, true, 1u << 25, true)];
   char kName[32], kvName[32];
   ConfigName(k, kName, sizeof(kName));
   ConfigName(kv, kvName, sizeof(kvName));

@@ -45,10 +45,6 @@ struct TileConfig {
 constexpr int kNumTileConfigs = 4;
 extern const TileConfig kTileConfigs[kNumTileConfigs];
 
-// Tail split (vrdx_layout.h, PlanTiles): applied while what is left behind the whole rounds is at most this share of a
-// round (profiles/r04_tail_split.txt).
-constexpr uint32_t kTailSplitPercent = 100;
-
 // Every spin is bounded: a look-back that makes no progress for this many trips sets the failure word and goes on
 // (result unspecified) instead of hanging the GPU.
 constexpr uint32_t kSpinLimit = 1u << 18;
@@ -122,6 +118,10 @@ hipError_t LaunchBucketSort(hipStream_t stream, bool keyValue, bool atomicRank, 
 // Runs the device self-check of the LDS same-address atomic ordering on the current device
 // (synchronous, ~1 ms).  *laneOrdered = true when returning atomics are served in lane order.
 hipError_t LdsOrderCheck(bool* laneOrdered);
+// The same check, small (8 workgroups, ~20 us) and stream-ordered: a mismatch sets bit 1 of *sticky.  Never blocks.
+hipError_t LaunchLdsOrderRecheck(hipStream_t stream, uint32_t* sticky);
+// One wave that runs for `ticks` ticks of the device's constant-rate wall clock and stores its first and last reading.
+hipError_t LaunchSpin(hipStream_t stream, unsigned long long* out, uint32_t ticks);
 
 }  // namespace vrdx
 

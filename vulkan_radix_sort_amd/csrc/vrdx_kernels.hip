@@ -583,6 +583,19 @@ __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t ti
   return exclusive;
 }
 
+// Test build only (-DVRDX_TESTING, tests/sticky_status_check.py): with a spin limit of 0 the first look-back trip that
+// finds a predecessor unpublished gives up, and tile 0 holds its inclusive prefix back for ~0.3 ms, so that tile 1 is
+// CERTAIN to find it unpublished -- the failure path is then exercised deterministically, not "in practice".
+__device__ __forceinline__ void TestDelayFirstTile(uint32_t tile, uint32_t spinLimit) {
+#ifdef VRDX_TESTING
+  if (spinLimit == 0 && tile == 0)
+    for (int i = 0; i < 100; ++i) __builtin_amdgcn_s_sleep(127);
+#else
+  (void)tile;
+  (void)spinLimit;
+#endif
+}
+
 // Stable rank of one key slot inside its wave, two interchangeable ways (same results):
 //
 //  * RankBallot  -- match-any with 8 ballots; leader lane bumps the wave-private digit counter.
@@ -1084,6 +1097,7 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   uint32_t lookBackTrace = 0;
   if (tile != 0)
     exclusive = LookBack<THREADS>(a.statusCur, tile, tid, waveHist, a.failure, a.stickyFailure, a.spinLimit, &lookBackTrace);
+  TestDelayFirstTile(tile, a.spinLimit);
   if (tid < 256) {
     if (!lastTile)
       StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid],
@@ -1318,6 +1332,7 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
   if (tile != 0)
     exclusive = LookBack<THREADS>(a.statusCur, tile, tid, lookScratch, a.failure, a.stickyFailure, a.spinLimit,
                                   &lookBackTrace);
+  TestDelayFirstTile(tile, a.spinLimit);
   if (tid < 256) {
     if (!lastTile)
       StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid],
@@ -1583,7 +1598,9 @@ __device__ __forceinline__ uint32_t OrderCheckKey(uint32_t tid, uint32_t wave, u
   return x & mask;
 }
 
-__global__ __launch_bounds__(1024) void lds_order_check_kernel(uint32_t* mismatches) {
+// sticky (the periodic re-check recorded behind every 65536th sort, vrdx_api.cpp): a mismatch sets bit 1 of the sorter's
+// status word instead of being counted.
+__global__ __launch_bounds__(1024) void lds_order_check_kernel(uint32_t* mismatches, uint32_t* sticky) {
   __shared__ uint32_t counters[2 * 16 * 256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < 2 * 16 * 256; i += 1024) counters[i] = 0;
@@ -1620,7 +1637,28 @@ __global__ __launch_bounds__(1024) void lds_order_check_kernel(uint32_t* mismatc
       for (int i = 0; i < 16; ++i) bad += rp[i] != want[i];
     }
   }
-  if (bad != 0) atomicAdd(mismatches, bad);
+  if (bad != 0) {
+    if (mismatches != nullptr) atomicAdd(mismatches, bad);
+    if (sticky != nullptr) atomicOr(sticky, 2u);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// a kernel of KNOWN duration, for calibrating what a pair of HIP events adds to the kernel between them
+// ---------------------------------------------------------------------------------------------
+// One wave spins on the constant-rate wall clock (100 MHz on gfx950) for `ticks` ticks and leaves its first and last
+// reading: out[1] - out[0] is the time the kernel demonstrably ran.  vrdxHipEventOverheadNs brackets it with two events.
+__global__ __launch_bounds__(64) void spin_kernel(unsigned long long* out, uint32_t ticks) {
+  const unsigned long long t0 = wall_clock64();
+  unsigned long long t = t0;
+  while (t - t0 < ticks) {
+    __builtin_amdgcn_s_sleep(1);
+    t = wall_clock64();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = t0;
+    out[1] = t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1751,11 +1789,21 @@ hipError_t LdsOrderCheck(bool* laneOrdered) {
   if (e != hipSuccess) return e;
   uint32_t h = 0xFFFFFFFFu;
   e = hipMemset(d, 0, sizeof(uint32_t));
-  if (e == hipSuccess) e = Launch(reinterpret_cast<const void*>(&lds_order_check_kernel), 512, 1024, 0, nullptr, d);
+  uint32_t* const noSticky = nullptr;
+  if (e == hipSuccess) e = Launch(reinterpret_cast<const void*>(&lds_order_check_kernel), 512, 1024, 0, nullptr, d, noSticky);
   if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof(uint32_t), hipMemcpyDeviceToHost);
   (void)hipFree(d);
   if (e == hipSuccess) *laneOrdered = h == 0;
   return e;
+}
+
+hipError_t LaunchLdsOrderRecheck(hipStream_t stream, uint32_t* sticky) {
+  uint32_t* const noCount = nullptr;
+  return Launch(reinterpret_cast<const void*>(&lds_order_check_kernel), 8, 1024, 0, stream, noCount, sticky);
+}
+
+hipError_t LaunchSpin(hipStream_t stream, unsigned long long* out, uint32_t ticks) {
+  return Launch(reinterpret_cast<const void*>(&spin_kernel), 1, 64, 0, stream, out, ticks);
 }
 
 // ---- single-launch path for small sorts ---------------------------------------------------------
