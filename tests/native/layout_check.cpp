@@ -49,15 +49,20 @@ int main() {
         }
         for (uint32_t address = 0; address < 128; address += 16) {
           if (!allAlignments && address != 0 && address != 32 && address != 112) continue;
-          const vrdx::StorageLayout l = vrdx::MakeLayout(n, VRDX_STORAGE_ALIGN, plan.tiles, 0x7f0000001000ull + address);
+          const vrdx::StorageLayout l =
+              vrdx::MakeLayout(n, VRDX_STORAGE_ALIGN, plan.tiles, 0x7f0000001000ull + address, plan.blockSums);
           ++cases;
-          const uint64_t region1End = l.statusOffset + 2 * l.statusRows * 1024;
+          // block sums: sorts of one round of 64 ... cus tiles of 32768 keys and more; one more row per 32 tiles
+          ok = ok && l.blockRows == (plan.blockSums ? (plan.tiles + 31) / 32 : 0);
+          ok = ok && (!plan.blockSums || (plan.tiles >= 64 && plan.tiles <= cus && plan.fullTiles == ~0u));
+          ok = ok && l.regionBytes == (l.statusRows + l.blockRows) * 1024;
+          const uint64_t region1End = l.statusOffset + 2 * l.regionBytes;
           const uint64_t inoutBytes = (uint64_t)n * 4;
           ok = ok && l.keysOnlySize == vrdx_oracle_storage_size(n, VRDX_STORAGE_ALIGN, 0);
           ok = ok && l.keyValueSize == vrdx_oracle_storage_size(n, VRDX_STORAGE_ALIGN, 1);
           ok = ok && l.histogramOffset == 16 && l.statusOffset >= 16 + 4096 && l.statusOffset < 16 + 4096 + 128;
           ok = ok && l.statusRows == (plan.tiles > 0 ? plan.tiles - 1 : 0);
-          ok = ok && l.clearBytes == l.statusOffset + l.statusRows * 1024;
+          ok = ok && l.clearBytes == 16 + 4096 && l.statusClearBytes == l.regionBytes;
           ok = ok && (address + l.statusOffset) % 128 == 0;            // status rows start on a line
           ok = ok && l.ticketOffset == region1End;                     // the ticket line: its own, right behind them
           ok = ok && l.inoutOffset == l.ticketOffset + 128;

@@ -294,9 +294,15 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   const bool atomicRank = sorter->atomicRank.load(std::memory_order_relaxed);  // one answer for the whole sort
   const int configIndex = ConfigIndex(sorter, keyValue, elementCount, atomicRank);
   const vrdx::TilePlan tilePlan = PlanTiles(sorter, configIndex, keyValue, elementCount, atomicRank);
+  const uint32_t hybridCap = ForcedConfigIndex() < 0 ? HybridCapacity(atomicRank, elementCount) : 0u;
+  // Block sums instead of the look-back chain: sorts of one round (PlanTiles) on the four-pass plan -- with a hybrid
+  // plan recorded, launch 0 may rank by another byte than its pass index, which the block-sum form does not look up.
+  // VRDX_BLOCK_SUMS=0 keeps the classic look-back (measurements).
+  static const int blockSumsKnob = TuningKnob("VRDX_BLOCK_SUMS");
+  const bool blockSums = tilePlan.blockSums && hybridCap == 0 && blockSumsKnob != 0;
   uint8_t* const storage = BufferAddress(storageBuffer, storageOffset);
-  const vrdx::StorageLayout layout = vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment,
-                                                      tilePlan.tiles, (uint64_t)reinterpret_cast<uintptr_t>(storage));
+  const vrdx::StorageLayout layout = vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, tilePlan.tiles,
+                                                      (uint64_t)reinterpret_cast<uintptr_t>(storage), blockSums);
   uint32_t* const keys = reinterpret_cast<uint32_t*>(BufferAddress(keysBuffer, keysOffset));
   uint32_t* const values =
       keyValue ? reinterpret_cast<uint32_t*>(BufferAddress(valuesBuffer, valuesOffset)) : nullptr;
@@ -326,8 +332,8 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     return;
   }
 
-  // Clear count/failure word, the 4x256 global histogram (reference :382) and status
-  // region 0 in one fill.  Indirect: also copy the device-side count to where the reference keeps
+  // Clear count / plan / failure word and the 4x256 global histogram (reference :382) in one fill of 4112 bytes; status
+  // region 0 is zeroed by the histogram kernel behind it.  Indirect: also copy the device-side count to where the reference keeps
   // it (:368-379); the kernels themselves read it straight from the caller's buffer.  (Direct: the
   // count travels as a kernel argument, the slot stays 0 -- storage contents are scratch.)
   EnqueueCheck(sorter, "hipMemsetAsync(state)", hipMemsetAsync(storage, 0, layout.clearBytes, stream));
@@ -361,11 +367,11 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     static const int forcedGrid = TuningKnob("VRDX_HIST_GRID");  // tools/hist_grid.sh
     if (forcedGrid > 0) grid = (uint32_t)forcedGrid;
     EnqueueCheck(sorter, "histogram_kernel",
-                 vrdx::LaunchHistogram(stream, grid, keys, elementCount, countPtr, globalHistogram, tickets));
+                 vrdx::LaunchHistogram(stream, grid, keys, elementCount, countPtr, globalHistogram, tickets, status,
+                                       (uint32_t)layout.statusClearBytes));
   }
 
   const uint32_t tiles = tilePlan.tiles;
-  const uint32_t hybridCap = ForcedConfigIndex() < 0 ? HybridCapacity(atomicRank, elementCount) : 0u;
   // Key+value tiles fetch their values early (right after the ranking: they land during the scan and the
   // regroup) -- on the final kernels that is as fast as or faster than fetching them after the
   // look-back at every size (0-8 %, vrdx_selftest sweep with VRDX_KV_EARLY_VALUES=0|1); the late form
@@ -408,10 +414,16 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     args.maxCount = elementCount;
     args.countPtr = countPtr;
     args.histogramTable = globalHistogram;
-    args.statusCur = status + (size_t)(pass & 1u) * statusRows * VRDX_RADIX;
-    args.statusNext =
-        pass + 1 < VRDX_PASSES ? status + (size_t)((pass + 1) & 1u) * statusRows * VRDX_RADIX : nullptr;
+    // region r of the two: [statusRows tile rows][blockRows block rows]
+    const size_t regionWords = (size_t)(layout.regionBytes / sizeof(uint32_t));
+    uint32_t* const regionCur = status + (size_t)(pass & 1u) * regionWords;
+    uint32_t* const regionNext = status + (size_t)((pass + 1) & 1u) * regionWords;
+    args.statusCur = regionCur;
+    args.statusNext = pass + 1 < VRDX_PASSES ? regionNext : nullptr;
     args.statusRows = statusRows;
+    args.blockCur = blockSums ? regionCur + (size_t)statusRows * VRDX_RADIX : nullptr;
+    args.blockNext = blockSums ? regionNext + (size_t)statusRows * VRDX_RADIX : nullptr;
+    args.blockRows = blockSums ? (uint32_t)layout.blockRows : 0u;
     args.ticketCur = tickets + (pass & 1u);
     args.ticketNext = tickets + ((pass + 1) & 1u);
     args.failure = failure;

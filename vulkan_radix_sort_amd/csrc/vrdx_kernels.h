@@ -63,6 +63,11 @@ struct OnesweepArgs {
   uint32_t* statusCur;        // status region of this pass: [statusRows][256]
   uint32_t* statusNext;       // region to clear for the next pass, or nullptr on the last pass
   uint32_t statusRows;
+  // Block sums (sorts of one round on the four-pass plan, BlockPrefix in vrdx_kernels.hip): one row per VRDX_BLOCK_TILES
+  // tiles behind the tile rows of each status region; nullptr / 0: the classic look-back.
+  uint32_t* blockCur;
+  uint32_t* blockNext;
+  uint32_t blockRows;
   uint32_t* ticketCur;
   uint32_t* ticketNext;
   uint32_t* failure;          // word in the caller's storage: this sort's (cleared when the next sort is recorded)
@@ -83,9 +88,11 @@ struct OnesweepArgs {
 // Raises the dynamic-LDS limit of both instantiations (keys-only, key-value) of one tile config.
 hipError_t PrepareKernels(int configIndex);
 
-// Also zeroes the two tile tickets (they live outside the cleared prefix of the storage).
+// Also zeroes the two tile tickets and status region 0 (statusClearBytes from statusClear, whole 1 KiB rows): they live
+// outside the prefix of the storage that the fill in front of this kernel clears.
 hipError_t LaunchHistogram(hipStream_t stream, uint32_t grid, const uint32_t* keys, uint32_t maxCount,
-                           const uint32_t* countPtr, uint32_t* globalHistogram, uint32_t* tickets);
+                           const uint32_t* countPtr, uint32_t* globalHistogram, uint32_t* tickets, void* statusClear,
+                           uint32_t statusClearBytes);
 
 // atomicRank selects the one-LDS-atomic-per-key ranking; only legal when LdsOrderCheck() said so.
 hipError_t LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool keyValue, bool atomicRank,

@@ -76,6 +76,11 @@ __device__ __forceinline__ void StoreStatus(uint32_t* p, uint32_t v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// One tile's count of one digit into its block's row: arrivals in the top bits, sum below (no return value).
+__device__ __forceinline__ void AddToBlock(uint32_t* p, uint32_t count) {
+  (void)__hip_atomic_fetch_add(p, count | (1u << VRDX_BLOCK_COUNT_SHIFT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ uint32_t ElementCount(uint32_t maxCount, const uint32_t* countPtr) {
   if (countPtr == nullptr) return maxCount;
   const uint32_t c = *countPtr;
@@ -350,12 +355,18 @@ __device__ __forceinline__ void HistFetch(const u32x4* keys4, uint32_t group, ui
   }
 }
 
+// The kernel also zeroes status region 0 (statusVecs 16-byte vectors from statusClear, shared out over the workgroups)
+// and the two tickets: nothing reads them before pass 0, which starts when this kernel has drained.  Before round 4
+// the fill in front of the histogram cleared region 0 as well -- 1-2 MiB at N = 2^25, a 4.4 us fill kernel on the
+// critical path of every sort where 4 KiB (header + table, which the atomics below need zeroed) take 2 us.
 template <uint32_t COPIES>
 __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t* __restrict__ keys,
                                                                   uint32_t maxCount,
                                                                   const uint32_t* countPtr,
                                                                   uint32_t* __restrict__ globalHistogram,
-                                                                  uint32_t* __restrict__ tickets) {
+                                                                  uint32_t* __restrict__ tickets,
+                                                                  u32x4* __restrict__ statusClear,
+                                                                  uint32_t statusVecs) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* const bins = smem;  // [pass][digit][copy]
   const uint32_t tid = threadIdx.x;
@@ -417,6 +428,9 @@ __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t*
     sweep(std::false_type{});
   }
   if (blockIdx.x == 0 && tid < (n & 3u)) count(keys[(nvec << 2) + tid]);
+  // status region 0: issued behind the key loads, drained with them
+  for (uint32_t i = blockIdx.x * kHistThreads + tid; i < statusVecs; i += gridDim.x * kHistThreads)
+    statusClear[i] = u32x4{0u, 0u, 0u, 0u};
   __syncthreads();
 
   for (uint32_t b = tid; b < VRDX_PASSES * VRDX_RADIX; b += kHistThreads) {
@@ -581,6 +595,71 @@ __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t ti
   }
   if (traceTripsRows != nullptr && tid == 0) *traceTripsRows = (traceTrips << 16) | (traceRows & 0xFFFFu);
   return exclusive;
+}
+
+// Block sums: the prefix of a tile WITHOUT the chain of inclusive prefixes -- sorts of ONE round of tiles.
+//
+// When all tiles of a pass start together (one per CU) every tile publishes its aggregate at about the same moment,
+// and the classic look-back then waits for inclusive prefixes to spread tile by tile: tile i needs ~i/64 dependent
+// trips (2.3-2.9 on average, 4-6 for the high tiles of the round, ~1.5 us each).  Here every tile also ADDS its 256
+// counts to the row of its block of VRDX_BLOCK_TILES consecutive tiles (one no-return agent-scope atomic per digit; the
+// word counts the arrivals in its top bits), and a tile's prefix is
+//     the global digit base  +  the complete block rows before its block  +  the aggregates of the tiles before it in
+//     its block:
+// at most 31 + 31 words per digit, all of which exist as soon as the predecessors have PUBLISHED -- no tile waits for
+// another tile's look-back.  Groups 0 and 1 (256 threads each, one per digit) add up the tile rows, groups 2 and 3 the
+// block rows, 16 words per thread, each thread on its own (no barrier inside the loop).  Measured in round 2 on
+// experiment/block-prefix (1.46 instead of 2.3 trips per tile; +2 ... +8 % at 2^22.5 ... 2^24 keys, -3 % at 2^25 and
+// beyond, where later rounds find inclusive prefixes waiting for them), adopted in round 4 for sorts of one round
+// (PlanTiles / MakeLayout decide: 64 ... CUs tiles of 32768 keys and more, four-pass plan).
+// Returns the sum in the threads tid < 256; contains one barrier.
+template <int THREADS>
+__device__ __forceinline__ uint32_t BlockPrefix(const uint32_t* status, const uint32_t* blocks, uint32_t tile, int tid,
+                                                uint32_t* lds, uint32_t* failure, uint32_t* stickyFailure,
+                                                uint32_t spinLimit, uint32_t* traceTripsRows) {
+  static_assert(THREADS == 1024, "two groups for the tile rows, two for the block rows");
+  constexpr uint32_t W = VRDX_BLOCK_TILES / 2;
+  const uint32_t g = (uint32_t)tid >> 8;
+  const uint32_t d = (uint32_t)tid & 255u;
+  const uint32_t block = tile / VRDX_BLOCK_TILES;
+  const bool blockRows = g >= 2;
+  const uint32_t span = blockRows ? block : tile % VRDX_BLOCK_TILES;  // rows of my kind to add up
+  const uint32_t half = (g & 1u) * W;
+  uint32_t lo = half < span ? half : span;
+  const uint32_t hi = half + W < span ? half + W : span;
+  const uint32_t* const rows = (blockRows ? blocks : status + (size_t)block * VRDX_BLOCK_TILES * VRDX_RADIX) + d;
+  uint32_t sum = 0, spins = 0, trips = 0;
+  while (lo < hi) {
+    uint32_t v[W];
+#pragma unroll
+    for (uint32_t k = 0; k < W; ++k) v[k] = lo + k < hi ? LoadStatus(&rows[(size_t)(lo + k) * VRDX_RADIX]) : 0u;
+    uint32_t consumed = 0;
+    bool open = true;
+#pragma unroll
+    for (uint32_t k = 0; k < W; ++k) {
+      const bool ready = blockRows ? (v[k] >> VRDX_BLOCK_COUNT_SHIFT) == VRDX_BLOCK_TILES
+                                   : (v[k] >> VRDX_FLAG_SHIFT) != VRDX_FLAG_EMPTY;
+      open = open && lo + k < hi && ready;
+      if (open) {
+        sum += v[k] & (blockRows ? VRDX_BLOCK_SUM_MASK : VRDX_VALUE_MASK);
+        ++consumed;
+      }
+    }
+    lo += consumed;
+    ++trips;
+    if (consumed == 0) {
+      if (++spins > spinLimit) {
+        atomicOr(failure, 1u);  // bounded, like the look-back: give up rather than hang the GPU
+        if (stickyFailure != nullptr) atomicOr(stickyFailure, 1u);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  lds[g * 256u + d] = sum;
+  if (traceTripsRows != nullptr && tid == 0) *traceTripsRows = (trips << 16) | (span & 0xFFFFu);
+  LdsBarrier();
+  return g == 0 ? lds[d] + lds[256u + d] + lds[512u + d] + lds[768u + d] : 0u;
 }
 
 // Test build only (-DVRDX_TESTING, tests/sticky_status_check.py): with a spin limit of 0 the first look-back trip that
@@ -952,6 +1031,7 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   uint32_t* const scanScratch = smem;                               // 8   (before the regroup)
   uint32_t* const misc = smem + 8;                                  // [0] ticket (before the regroup)
   uint32_t* const planFlags = smem + 16;                            // 32 (before the regroup)
+  uint32_t* const passDigitCounts = smem + 64;                      // 256 (before the regroup; block sums only)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -977,6 +1057,14 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   const PassCounts<THREADS> passCounts = LoadPassCounts<THREADS>(a.histogramTable, tid);
   if (tid == 0) misc[0] = atomicAdd(a.ticketCur, 1u);
   PublishPassVotes<THREADS>(passCounts, n, a.hybridCap, tid, planFlags);
+  // block sums (sorts of one round, four-pass plan only: the digit is the pass): every tile needs this pass's 256 global
+  // counts for the digit base -- they are in the registers of the threads [256 * pass, 256 * pass + 256) already
+  // (built into the 32768-key geometry only, the one the plan ever selects it for: the smaller ones have no register to spare)
+  constexpr bool kBlockSumsBuilt = THREADS == 1024 && KPT == 32;
+  const bool blockSums = kBlockSumsBuilt && a.blockCur != nullptr;
+  if constexpr (kBlockSumsBuilt) {
+    if (blockSums && ((uint32_t)tid >> 8) == a.pass) passDigitCounts[tid & 255] = passCounts.v[0];
+  }
   for (int i = tid; i < WAVES * 256; i += THREADS) waveHist[i] = 0;
   LdsBarrier();
   VRDX_STAMP(1);
@@ -997,6 +1085,7 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
     // (workgroup b stands in for tile b: there is no look-back here that would care).
     if (a.statusNext != nullptr) {
       if (tid < 256 && blockIdx.x < a.statusRows) a.statusNext[blockIdx.x * VRDX_RADIX + tid] = 0;
+      if (tid < 256 && blockIdx.x < a.blockRows) a.blockNext[blockIdx.x * VRDX_RADIX + tid] = 0;
       if (blockIdx.x == 0 && tid == 0) *a.ticketNext = 0;
     }
     return;
@@ -1016,6 +1105,7 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   // of the other status region and the other ticket.
   if (a.statusNext != nullptr) {
     if (tid < 256 && tile < a.statusRows) a.statusNext[tile * VRDX_RADIX + tid] = 0;
+    if (tid < 256 && tile < a.blockRows) a.blockNext[tile * VRDX_RADIX + tid] = 0;
     if (tile == 0 && tid == 0) *a.ticketNext = 0;
   }
 
@@ -1065,14 +1155,17 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) count += waveHist[w * 256 + tid];
     // Tile 0 never publishes a bare aggregate: its inclusive value carries the global digit base.
-    if (tile != 0 && !lastTile)
+    // (Block sums: every tile but the last publishes its aggregate and adds it to its block's row.)
+    if ((tile != 0 || blockSums) && !lastTile)
       StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid], (VRDX_FLAG_AGGREGATE << VRDX_FLAG_SHIFT) | count);
+    if (blockSums && !lastTile) AddToBlock(&a.blockCur[(tile / VRDX_BLOCK_TILES) * VRDX_RADIX + tid], count);
   }
   const uint32_t tileExclusive = BlockExclusiveScan256(tid < 256 ? count : 0u, scanScratch, tid);
   uint32_t exclusive = 0;
-  if (tile == 0) {
-    // spine.slang:62-83 equivalent: exclusive scan of this pass's 256 global digit counts.
-    const uint32_t g = tid < 256 ? a.histogramTable[plan.digit * VRDX_RADIX + tid] : 0u;
+  if (tile == 0 || blockSums) {
+    // spine.slang:62-83 equivalent: exclusive scan of this pass's 256 global digit counts (block sums: by every tile,
+    // the chain that would carry the base along from tile 0 does not exist)
+    const uint32_t g = tid < 256 ? (blockSums ? passDigitCounts[tid] : a.histogramTable[plan.digit * VRDX_RADIX + tid]) : 0u;
     exclusive = BlockExclusiveScan256(g, scanScratch + 4, tid);
   }
   if (tid < 256) {
@@ -1095,11 +1188,16 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
 
   // ---- decoupled look-back over the preceding tiles, then publish the inclusive prefix --------
   uint32_t lookBackTrace = 0;
-  if (tile != 0)
+  if constexpr (kBlockSumsBuilt) {
+    if (blockSums && tile != 0)
+      exclusive += BlockPrefix<THREADS>(a.statusCur, a.blockCur, tile, tid, waveHist, a.failure, a.stickyFailure, a.spinLimit,
+                                        &lookBackTrace);
+  }
+  if (!blockSums && tile != 0)
     exclusive = LookBack<THREADS>(a.statusCur, tile, tid, waveHist, a.failure, a.stickyFailure, a.spinLimit, &lookBackTrace);
   TestDelayFirstTile(tile, a.spinLimit);
   if (tid < 256) {
-    if (!lastTile)
+    if (!lastTile && !blockSums)
       StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid],
                   (VRDX_FLAG_INCLUSIVE << VRDX_FLAG_SHIFT) | ((exclusive + count) & VRDX_VALUE_MASK));
     tileOffset[tid] = exclusive - tileExclusive;
@@ -1209,6 +1307,12 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
   const PassCounts<THREADS> passCounts = LoadPassCounts<THREADS>(a.histogramTable, tid);
   if (tid == 0) misc[0] = atomicAdd(a.ticketCur, 1u);
   PublishPassVotes<THREADS>(passCounts, n, a.hybridCap, tid, misc + 1);
+  // block sums (see onesweep_kernel): this pass's 256 global counts, parked in the idle staging buffer
+  const bool blockSums = THREADS == 1024 && a.blockCur != nullptr;
+  uint32_t* const passDigitCounts = sorted + 64;
+  if constexpr (THREADS == 1024) {
+    if (blockSums && ((uint32_t)tid >> 8) == a.pass) passDigitCounts[tid & 255] = passCounts.v[0];
+  }
   for (int i = tid; i < WAVES * 256; i += THREADS) waveHist[i] = 0;
   LdsBarrier();
   VRDX_STAMP(1);
@@ -1221,6 +1325,7 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
   if (plan.skip) {  // see onesweep_kernel
     if (a.statusNext != nullptr) {
       if (tid < 256 && blockIdx.x < a.statusRows) a.statusNext[blockIdx.x * VRDX_RADIX + tid] = 0;
+      if (tid < 256 && blockIdx.x < a.blockRows) a.blockNext[blockIdx.x * VRDX_RADIX + tid] = 0;
       if (blockIdx.x == 0 && tid == 0) *a.ticketNext = 0;
     }
     return;
@@ -1240,6 +1345,7 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
 
   if (a.statusNext != nullptr) {
     if (tid < 256 && tile < a.statusRows) a.statusNext[tile * VRDX_RADIX + tid] = 0;
+    if (tid < 256 && tile < a.blockRows) a.blockNext[tile * VRDX_RADIX + tid] = 0;
     if (tile == 0 && tid == 0) *a.ticketNext = 0;
   }
 
@@ -1276,9 +1382,9 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
   }
   const uint32_t localA = BlockExclusiveScan256(tid < 256 ? countA : 0u, scanScratch, tid);
   uint32_t exclusive = 0;
-  if (tile == 0) {
-    // spine.slang:62-83 equivalent: exclusive scan of this pass's 256 global digit counts.
-    const uint32_t g = tid < 256 ? a.histogramTable[plan.digit * VRDX_RADIX + tid] : 0u;
+  if (tile == 0 || blockSums) {
+    // spine.slang:62-83 equivalent: exclusive scan of this pass's 256 global digit counts (block sums: by every tile)
+    const uint32_t g = tid < 256 ? (blockSums ? passDigitCounts[tid] : a.histogramTable[plan.digit * VRDX_RADIX + tid]) : 0u;
     exclusive = BlockExclusiveScan256(g, scanScratch + 4, tid);
   }
   if (tid < 256) {
@@ -1310,9 +1416,10 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
   if (tid < 256) {
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) countB += waveHist[w * 256 + tid];
-    if (tile != 0 && !lastTile)
+    if ((tile != 0 || blockSums) && !lastTile)
       StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid],
                   (VRDX_FLAG_AGGREGATE << VRDX_FLAG_SHIFT) | (countA + countB));
+    if (blockSums && !lastTile) AddToBlock(&a.blockCur[(tile / VRDX_BLOCK_TILES) * VRDX_RADIX + tid], countA + countB);
   }
   const uint32_t localB = BlockExclusiveScan256(tid < 256 ? countB : 0u, scanScratch, tid);
   if (tid < 256) {
@@ -1329,12 +1436,17 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
 
   // ---- one look-back for both sub-tiles ----------------------------------------------------------
   uint32_t lookBackTrace = 0;
-  if (tile != 0)
+  if constexpr (THREADS == 1024) {
+    if (blockSums && tile != 0)
+      exclusive += BlockPrefix<THREADS>(a.statusCur, a.blockCur, tile, tid, lookScratch, a.failure, a.stickyFailure,
+                                        a.spinLimit, &lookBackTrace);
+  }
+  if (!blockSums && tile != 0)
     exclusive = LookBack<THREADS>(a.statusCur, tile, tid, lookScratch, a.failure, a.stickyFailure, a.spinLimit,
                                   &lookBackTrace);
   TestDelayFirstTile(tile, a.spinLimit);
   if (tid < 256) {
-    if (!lastTile)
+    if (!lastTile && !blockSums)
       StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid],
                   (VRDX_FLAG_INCLUSIVE << VRDX_FLAG_SHIFT) | ((exclusive + countA + countB) & VRDX_VALUE_MASK));
     offsetA[tid] = exclusive - localA;
@@ -1915,12 +2027,15 @@ hipError_t LaunchBucketSort(hipStream_t stream, bool keyValue, bool atomicRank, 
 }
 
 hipError_t LaunchHistogram(hipStream_t stream, uint32_t grid, const uint32_t* keys, uint32_t maxCount,
-                           const uint32_t* countPtr, uint32_t* globalHistogram, uint32_t* tickets) {
+                           const uint32_t* countPtr, uint32_t* globalHistogram, uint32_t* tickets, void* statusClear,
+                           uint32_t statusClearBytes) {
+  u32x4* const clear = reinterpret_cast<u32x4*>(statusClear);
+  const uint32_t vecs = statusClearBytes / 16u;  // whole status rows: a multiple of 1 KiB, 128-byte aligned
   if (maxCount >= kHistManyCopiesFrom)
     return Launch(reinterpret_cast<const void*>(&histogram_kernel<kHistCopiesLarge>), grid, kHistThreads,
-                  HistLdsBytes(kHistCopiesLarge), stream, keys, maxCount, countPtr, globalHistogram, tickets);
+                  HistLdsBytes(kHistCopiesLarge), stream, keys, maxCount, countPtr, globalHistogram, tickets, clear, vecs);
   return Launch(reinterpret_cast<const void*>(&histogram_kernel<kHistCopies>), grid, kHistThreads,
-                HistLdsBytes(kHistCopies), stream, keys, maxCount, countPtr, globalHistogram, tickets);
+                HistLdsBytes(kHistCopies), stream, keys, maxCount, countPtr, globalHistogram, tickets, clear, vecs);
 }
 
 hipError_t LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool keyValue, bool atomicRank,

@@ -55,6 +55,12 @@
 #define VRDX_FLAG_AGGREGATE 1u
 #define VRDX_FLAG_INCLUSIVE 2u
 
+/* block sums (sorts of one round): one row per VRDX_BLOCK_TILES tiles, word = arrivals << VRDX_BLOCK_COUNT_SHIFT | sum of counts */
+#define VRDX_BLOCK_TILES 32u
+#define VRDX_BLOCK_COUNT_SHIFT 26u
+#define VRDX_BLOCK_SUM_MASK 0x03FFFFFFu
+#define VRDX_BLOCK_PREFIX_MIN_TILES 64u
+
 #define VRDX_MAX_ELEMENTS 0x3FFFFFFCu /* 2^30 - 4: beyond it the reference's uint32 Align(4 * N, 16) wraps (:105-115) */
 
 /* offsets inside the first 16 bytes */
@@ -88,9 +94,12 @@ struct StorageLayout {
   uint64_t ticketOffset;     // uint32[2], zeroed by the histogram kernel
   uint64_t failureOffset;    // uint32
   uint64_t histogramOffset;  // uint32[4][256]
-  uint64_t statusOffset;     // uint32[2][rows][256]
-  uint64_t statusRows;       // rows per region = max(tiles - 1, 0)
-  uint64_t clearBytes;       // bytes from storageOffset zeroed before every sort
+  uint64_t statusOffset;     // uint32[2][rows + blockRows][256]: tile rows, then block rows, per region
+  uint64_t statusRows;       // tile rows per region = max(tiles - 1, 0)
+  uint64_t blockRows;        // block-sum rows per region (one per 32 tiles); 0 = classic look-back
+  uint64_t regionBytes;      // (statusRows + blockRows) KiB
+  uint64_t clearBytes;       // bytes from storageOffset zeroed by the fill in front of every sort: header + global histogram
+  uint64_t statusClearBytes; // status region 0, zeroed by the histogram kernel (pass 0 is its first reader)
   uint64_t inoutOffset;      // keys scratch
   uint64_t valuesOffset;     // values scratch (KV only)
   uint64_t keysOnlySize;     // total storage, keys-only
@@ -99,8 +108,9 @@ struct StorageLayout {
 
 // tiles: status rows are sized for this many tiles (PlanTiles); storageAddress: the absolute address of the storage
 // (buffer + storageOffset) -- only its low 7 bits matter; the sizes do not depend on it.
+// blockSums: the sort uses block sums (PlanTiles said so): one more row per 32 tiles in each status region.
 static inline StorageLayout MakeLayout(uint32_t maxElementCount, uint32_t align, uint64_t tiles,
-                                       uint64_t storageAddress = 0) {
+                                       uint64_t storageAddress = 0, bool blockSums = false) {
   StorageLayout l;
   const uint64_t elementCountSize = Align((uint32_t)sizeof(uint32_t), align);
   const uint64_t histogramSize = HistogramSize(maxElementCount, align);
@@ -111,9 +121,13 @@ static inline StorageLayout MakeLayout(uint32_t maxElementCount, uint32_t align,
   const uint64_t tableEnd = l.histogramOffset + VRDX_PASSES * VRDX_RADIX * sizeof(uint32_t);
   l.statusOffset = tableEnd + ((0 - (storageAddress + tableEnd)) & 127u);
   l.statusRows = tiles > 0 ? tiles - 1 : 0;
-  // count + failure + global histogram + status region 0
-  l.clearBytes = l.statusOffset + l.statusRows * VRDX_RADIX * sizeof(uint32_t);
-  l.ticketOffset = l.statusOffset + 2 * l.statusRows * VRDX_RADIX * sizeof(uint32_t);
+  l.blockRows = blockSums ? (tiles + VRDX_BLOCK_TILES - 1) / VRDX_BLOCK_TILES : 0;
+  l.regionBytes = (l.statusRows + l.blockRows) * VRDX_RADIX * sizeof(uint32_t);
+  // count + plan word + failure word + global histogram: what the histogram kernel's atomics and the passes' first
+  // reads need zeroed BEFORE that kernel starts; status region 0 is zeroed by the histogram kernel itself
+  l.clearBytes = tableEnd;
+  l.statusClearBytes = l.regionBytes;
+  l.ticketOffset = l.statusOffset + 2 * l.regionBytes;
   l.inoutOffset = l.ticketOffset + 128;
   l.valuesOffset = l.inoutOffset + (((uint64_t)maxElementCount * sizeof(uint32_t) + 127u) & ~(uint64_t)127u);
   // the reference's totals (what the caller allocates)
@@ -137,7 +151,13 @@ struct TilePlan {
   uint32_t slots;      // 0: every tile holds the kernel's capacity (the kernels without run-time slot counts)
   uint32_t fullTiles;  // tiles [0, fullTiles) hold `slots` slots per wave (and sub-tile), the rest tailSlots
   uint32_t tailSlots;
+  bool blockSums;      // one round of 64 ... cus tiles of 32768 keys and more: block sums instead of the look-back chain
 };
+
+// Block sums pay when all tiles of a pass start together, i.e. in sorts of one round (BlockPrefix in vrdx_kernels.hip).
+static inline bool BlockSumsApply(uint32_t tiles, uint32_t cus, uint32_t tileKeys) {
+  return tileKeys >= 32768u && tiles >= VRDX_BLOCK_PREFIX_MIN_TILES && tiles <= cus;
+}
 
 // threads / keysPerThread / subTiles: the kernel's geometry; splitForms: its forms with run-time slot counts exist;
 // evenSplit: allowed; tailPercent: tail split while the rest is at most this share of a round (0: never).
@@ -150,6 +170,7 @@ static inline TilePlan PlanTiles(uint32_t elementCount, uint32_t cus, uint32_t t
   plan.slots = 0;
   plan.fullTiles = ~0u;
   plan.tailSlots = 0;
+  plan.blockSums = BlockSumsApply(plan.tiles, cus, capacity);
   if (elementCount == 0 || !splitForms || cus == 0) return plan;
   const uint32_t granule = 4u * slotKeys;  // the kernels walk four slots at a time
   const uint64_t round = (uint64_t)cus * capacity;
@@ -161,6 +182,7 @@ static inline TilePlan PlanTiles(uint32_t elementCount, uint32_t cus, uint32_t t
     if (slots >= keysPerThread) return plan;
     plan.slots = plan.tailSlots = slots;
     plan.tiles = RoundUp(elementCount, slots * slotKeys);
+    plan.blockSums = BlockSumsApply(plan.tiles, cus, slots * slotKeys);
     return plan;
   }
   if (tailPercent == 0) return plan;
@@ -173,6 +195,7 @@ static inline TilePlan PlanTiles(uint32_t elementCount, uint32_t cus, uint32_t t
   plan.fullTiles = fullTiles;
   plan.tailSlots = tailSlots;
   plan.tiles = fullTiles + RoundUp(rest, tailSlots * slotKeys);
+  plan.blockSums = false;  // more than one round
   return plan;
 }
 
