@@ -531,6 +531,37 @@ void Passes(Harness& h, int lg, bool kv, int runs) {
   }
 }
 
+// `count` sorts of 2^lg uniform keys, each on its own resident array, enqueued BACK TO BACK with no host synchronisation in
+// between (what bench.py's timed region does): prints the whole-batch rate.  Under `rocprofv3 --kernel-trace` the
+// per-kernel durations show what a kernel costs BEHIND another sort (tools/pass_parity.py).
+void BackToBack(Harness& h, int lg, bool kv, int count) {
+  const uint32_t n = 1u << lg;
+  const size_t inout = Align16(n * 4u);
+  VrdxSorterStorageRequirements req;
+  vrdxGetSorterKeyValueStorageRequirements(h.sorter, n, &req);
+  h.reserve((size_t)count * 2 * inout + 16, (size_t)req.size);
+  for (int i = 0; i < count; ++i) {
+    std::vector<uint32_t> v;
+    auto k = Mt(n, i + 1, 32, &v);
+    HIP_OK(hipMemcpy(h.dKeys + (size_t)i * 2 * inout, k.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(h.dKeys + (size_t)i * 2 * inout + inout, v.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  }
+  HIP_OK(hipDeviceSynchronize());
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < count; ++i) {
+    const VkDeviceSize at = (VkDeviceSize)i * 2 * inout;
+    if (kv)
+      vrdxCmdSortKeyValue((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, at, (VkBuffer)h.dKeys, at + inout,
+                          (VkBuffer)h.dStorage, 0, VK_NULL_HANDLE, 0);
+    else
+      vrdxCmdSort((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, at, (VkBuffer)h.dStorage, 0, VK_NULL_HANDLE, 0);
+  }
+  HIP_OK(hipStreamSynchronize(h.stream));
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  std::printf("n=%u %s: %d sorts back to back in %.4f ms = %.4f ms per sort, %.2f GItems/s\n", n, kv ? "kv" : "keys", count, ms,
+              ms / count, (double)n * count / (ms * 1e6));
+}
+
 // BASELINE.json configs[3]: N = 2^25 adversarial keys (all-equal, all-0xFFFFFFFF, descending,
 // few-distinct) against uniform random; values = iota, parity checked with the oracle for the
 // stable permutation, then timed (median of 5, data re-uploaded before every run).
@@ -720,6 +751,10 @@ int main(int argc, char** argv) {
   }
   if (what == "passes") {  // passes <log2n> [keys|kv] [runs]
     Passes(h, argc > 2 ? std::atoi(argv[2]) : 25, argc > 3 && std::string(argv[3]) == "kv", argc > 4 ? std::atoi(argv[4]) : 20);
+    return 0;
+  }
+  if (what == "backtoback") {  // backtoback <log2n> [keys|kv] [sorts]
+    BackToBack(h, argc > 2 ? std::atoi(argv[2]) : 25, argc > 3 && std::string(argv[3]) == "kv", argc > 4 ? std::atoi(argv[4]) : 10);
     return 0;
   }
   if (what == "soak") return Soak(h, argc > 2 ? std::atoi(argv[2]) : 30) ? 1 : 0;

@@ -500,6 +500,48 @@ def test_even_split_tiles_at_their_slot_boundaries(torch_mod, sorter, oracle, n)
     assert np.array_equal(gk, ek)
 
 
+ROUND = 256 * 32768   # one round of 32768-element tiles on the 256 CUs of an MI355X
+
+
+@pytest.mark.parametrize("n,key_value", [
+    (2 * ROUND + 1, False),                    # one key past one round of 65536-key tiles: a tail of ONE small tile holding one key
+    (2 * ROUND + 256 * 8192, False),           # 256 tail tiles of four slots per wave and sub-tile, all full
+    (2 * ROUND + 256 * 8192 + 1, False),       # one key more: eight slots
+    (4 * ROUND + 3 * 65536 + 12345, False),    # two whole rounds of the two-sub-tile kernel + a ragged tail
+    (2 * ROUND + 1, True),                     # key+value: two rounds of 32768 + one pair
+    (2 * ROUND + 256 * 4096 + 1, True),        # tail of eight slots
+    (3 * ROUND + ROUND // 2, True),            # the rest is exactly half a round: the last size the tail split takes
+    (3 * ROUND + ROUND // 2 + 4097, True),     # ... and past it: full tiles again
+])
+def test_tail_split_tiles_at_their_boundaries(torch_mod, sorter, oracle, n, key_value):
+    """Sorts of more than one round keep their whole rounds of full tiles and cut the rest into up to 256 small equal
+    tiles (PlanTiles in vrdx_layout.h; keys-only: the two-sub-tile kernel at every size, key+value: 1024x32 while the
+    rest is at most half a round).  Sizes that put one element, exactly full small tiles, one element more and a ragged
+    rest behind the whole rounds; direct, and indirect with a device-side count that ends inside the FULL tiles (every
+    tail tile and some full tiles start past the count) and one that ends inside the TAIL."""
+    k, v = oracle.generate(13, n, 32)
+    values = v if key_value else None
+    check_against_oracle(torch_mod, sorter, oracle, k, values)
+    whole = (n // ROUND) * ROUND if key_value else (n // (2 * ROUND)) * 2 * ROUND
+    for count in (whole - 70001, whole + (n - whole) // 2 + 1):
+        check_against_oracle(torch_mod, sorter, oracle, k, values, count=count, indirect=True, max_count=n)
+
+
+@pytest.mark.parametrize("n", [ROUND, ROUND + 4097, ROUND + ROUND // 4 + 3, 2 * ROUND - 5, 2 * ROUND])
+def test_block_sums_in_sorts_of_one_round(torch_mod, sorter, oracle, n):
+    """Sorts of ONE round of 64 ... 256 tiles of 32768 keys and more on the four-pass plan take their prefixes from block
+    sums instead of the look-back chain (BlockPrefix in vrdx_kernels.hip): 256 full 1024x32 tiles (keys-only and
+    key+value), the two-sub-tile kernel's even-split tiles from 129 tiles up to 256 full ones; direct and indirect with
+    a smaller count (whole blocks of 32 tiles past the count).  Values = iota: the permutation itself."""
+    k, _ = oracle.generate(17, n, 32)
+    iota = np.arange(n, dtype=np.uint32)
+    check_against_oracle(torch_mod, sorter, oracle, k)
+    check_against_oracle(torch_mod, sorter, oracle, k, iota)
+    count = n - n // 3 - 7
+    check_against_oracle(torch_mod, sorter, oracle, k, count=count, indirect=True, max_count=n)
+    check_against_oracle(torch_mod, sorter, oracle, k, iota, count=count, indirect=True, max_count=n)
+
+
 @pytest.mark.parametrize("n", [20_000, 70_001, 3_000_001, 9_000_001, (1 << 24) + 5])
 def test_two_valued_bytes_take_the_ballot_ranking(torch_mod, sorter, oracle, n):
     """Slots whose 64 digits are ONE or TWO values are ranked with ballots instead of a 32- or 64-way same-address

@@ -36,6 +36,12 @@ timeout 300 tests/native/vrdx_selftest soak 120 > $OUT/soak.txt 2>&1
 if [ "${WITH_DRIVER:-0}" = 1 ]; then  # (ten minutes each: the reference's sweep, 64 sizes x 11 runs x fresh mt19937 data)
   timeout 900 bench/bench hip --no-verify -o $OUT/bench_driver_hip.csv > $OUT/bench_driver_hip.log 2>&1
   timeout 900 bench/bench rocprim --no-verify -o $OUT/bench_driver_rocprim.csv > $OUT/bench_driver_rocprim.log 2>&1
+  # record once / submit many: every sort captured into a hipGraph once per (N, mode), the replay timed (cpu_ms column)
+  timeout 900 bench/bench hip --graph --no-verify -o $OUT/bench_driver_hip_graph.csv > $OUT/bench_driver_hip_graph.log 2>&1
 fi
+# 6. per-tile phase timelines of the headline kernels (the -DVRDX_TRACE build of `make -C vulkan_radix_sort_amd/csrc trace`)
+bash tools/trace.sh 1024x32x2 25 keys uniform > /dev/null 2>&1
+bash tools/trace.sh 1024x32 25 kv uniform > /dev/null 2>&1
+cp gpurun_out/trace_1024x32x2_keys_uniform.txt gpurun_out/trace_1024x32_kv_uniform.txt $OUT/ 2>/dev/null
 timeout 600 python3 -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
 if [ "${WITH_TESTS:-0}" = 1 ]; then timeout 1800 python3 -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; fi

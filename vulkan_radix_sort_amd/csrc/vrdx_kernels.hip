@@ -44,6 +44,12 @@ namespace vrdx {
 #ifndef VRDX_HIST_NT
 #define VRDX_HIST_NT 1
 #endif
+// Measurement only (profiles/r04_histogram_busy_stream.txt): the LAST pass of a sort scatters with non-temporal stores, so
+// that its output does not sit dirty in the caches when the next sort's histogram starts.  Off in the product: a
+// consumer of the sorted data wants it cached.
+#ifndef VRDX_NT_LAST_PASS
+#define VRDX_NT_LAST_PASS 0
+#endif
 
 
 // Timing-only phase trace for tools/trace.sh (never defined in the product build): thread 0 of
@@ -499,12 +505,17 @@ constexpr int kLookBackWindow = VRDX_LOOKBACK_WINDOW;
 constexpr int32_t kLookBackDone = INT32_MIN;
 
 // One 16-byte store of a sorted quad to out[index .. index + 3] (4-byte aligned).
-__device__ __forceinline__ void StoreQuad(uint32_t* out, uint32_t index, u32x4 q) {
+__device__ __forceinline__ void StoreQuad(uint32_t* out, uint32_t index, u32x4 q, bool nt = false) {
   u32x4_a4* const p = reinterpret_cast<u32x4_a4*>(reinterpret_cast<char*>(out) + (uint64_t)(index * 4u));
-  if (VRDX_NT_STORES)
+  if (VRDX_NT_STORES) {
     __builtin_nontemporal_store(q, p);
-  else
+  } else if (VRDX_NT_LAST_PASS && nt) {  // wave-uniform; the empty asm keeps the two kinds of store apart (see LoadTile)
+    asm volatile("; non-temporal scatter" ::: "memory");
+    __builtin_nontemporal_store(q, p);
+    asm volatile("" ::: "memory");
+  } else {
     *p = q;
+  }
 }
 
 template <int THREADS>
@@ -923,7 +934,7 @@ template <int THREADS, int KPT, bool KEEP_DIGITS, bool DYN = false>
 __device__ __forceinline__ void ScatterStagedKeys(const uint32_t* sorted, const uint32_t* offset, uint32_t* out,
                                                   uint32_t valid, uint32_t shift, int tid, uint32_t boundaryQuad,
                                                   uint32_t (&digits)[KEEP_DIGITS ? KPT / 4 : 1],
-                                                  uint32_t& boundaryDigits) {
+                                                  uint32_t& boundaryDigits, bool nt = false) {
   constexpr uint32_t STAGE = THREADS * KPT;
   constexpr int B = DYN ? (KPT % 16 == 0 ? 4 : 1) : ScatterBatch<KPT, KEEP_DIGITS>();
 #pragma unroll
@@ -945,7 +956,7 @@ __device__ __forceinline__ void ScatterStagedKeys(const uint32_t* sorted, const 
     }
 #pragma unroll
     for (int b = 0; b < B; ++b)
-      if (whole[b]) StoreQuad(out, o[b], k4[b]);
+      if (whole[b]) StoreQuad(out, o[b], k4[b], nt);
   }
   if (boundaryQuad != ~0u) {
     const u32x4 k4 = *reinterpret_cast<const u32x4*>(&sorted[StagingSlot<STAGE>(boundaryQuad)]);
@@ -958,7 +969,7 @@ __device__ __forceinline__ void ScatterStagedKeys(const uint32_t* sorted, const 
 template <int THREADS, int KPT, bool DYN = false>
 __device__ __forceinline__ void ScatterStagedValues(const uint32_t* sorted, const uint32_t* offset, uint32_t* out,
                                                     uint32_t valid, int tid, uint32_t boundaryQuad,
-                                                    const uint32_t (&digits)[KPT / 4], uint32_t boundaryDigits) {
+                                                    const uint32_t (&digits)[KPT / 4], uint32_t boundaryDigits, bool nt = false) {
   constexpr uint32_t STAGE = THREADS * KPT;
   constexpr int B = DYN ? (KPT % 16 == 0 ? 4 : 1) : ScatterBatch<KPT, false>();
 #pragma unroll
@@ -978,7 +989,7 @@ __device__ __forceinline__ void ScatterStagedValues(const uint32_t* sorted, cons
       const uint32_t p = StagingSlot<STAGE>(4u * (tid + (j0 + b) * THREADS));
       const uint32_t d0 = digits[j0 + b] & 0xFFu, d3 = digits[j0 + b] >> 8;
       if (p + 3 < valid && d0 == d3)
-        StoreQuad(out, o[b], v4[b]);
+        StoreQuad(out, o[b], v4[b], nt);
     }
   }
   if (boundaryQuad != ~0u)
@@ -1218,8 +1229,9 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   uint32_t digits[KV ? KPT / 4 : 1];  // key+value: first and last digit of every quad, for the value phase
   uint32_t boundaryDigits = 0;
   const uint32_t boundaryQuad = BoundaryQuad(tid, tileExclusive, count, valid);
+  const bool ntStores = VRDX_NT_LAST_PASS != 0 && a.pass == VRDX_PASSES - 1;
   ScatterStagedKeys<THREADS, KPT, KV, DYN>(sorted, tileOffset, keysOut, valid, shift, tid, boundaryQuad, digits,
-                                           boundaryDigits);
+                                           boundaryDigits, ntStores);
   if constexpr (KV) {
     LdsBarrier();  // every key has left the staging buffer
 #pragma unroll
@@ -1229,7 +1241,7 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
     }
     LdsBarrier();
     ScatterStagedValues<THREADS, KPT, DYN>(sorted, tileOffset, valuesOut, valid, tid, boundaryQuad, digits,
-                                           boundaryDigits);
+                                           boundaryDigits, ntStores);
   }
 #ifdef VRDX_TRACE
   VRDX_STAMP(6);
@@ -1460,15 +1472,16 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
   uint32_t boundaryDigits = 0;
   const uint32_t boundaryQuadA = BoundaryQuad(tid, localA, countA, validA);
   const uint32_t boundaryQuadB = BoundaryQuad(tid, localB, countB, validB);
+  const bool ntStores = VRDX_NT_LAST_PASS != 0 && a.pass == VRDX_PASSES - 1;
   ScatterStagedKeys<THREADS, KPT, false, DYN>(sorted, offsetA, keysOut, validA, shift, tid, boundaryQuadA, digits,
-                                              boundaryDigits);
+                                              boundaryDigits, ntStores);
   LdsBarrier();  // the staging buffer is free again
 
   // ---- B: regroup, scatter -----------------------------------------------------------------------
   RegroupKeys<KPT, SUB, PACKED, false, DYN>(keyB, rankB, shift, myHist, sorted, unusedSlots, slots);
   LdsBarrier();
   ScatterStagedKeys<THREADS, KPT, false, DYN>(sorted, offsetB, keysOut, validB, shift, tid, boundaryQuadB, digits,
-                                              boundaryDigits);
+                                              boundaryDigits, ntStores);
 #ifdef VRDX_TRACE
   VRDX_STAMP(6);
   if (a.trace != nullptr && tid == 0) {
@@ -1531,11 +1544,23 @@ __device__ __forceinline__ void SortInWorkgroup(const uint32_t* keysIn, uint32_t
     slots = slots < (uint32_t)KPT ? slots : (uint32_t)KPT;
   }
   const uint32_t first = wave * (slots * 64) + lane;  // element i of this lane: first + 64 * i
+  // A wave whose range starts at or behind n holds nothing but pads, before the sort and after every pass of it (pads
+  // carry the largest key and sit last in memory order): it skips every loop over its slots, and the wave that n cuts
+  // through walks only the chunks of four slots it has elements in.  The layout (first) stays that of `slots` slots per
+  // wave.  So the LDS work of a bucket follows its size in steps of 256 elements, not of 4096: without this a bucket of
+  // 16385 elements cost what 20480 cost (profiles/r04_bucket_granule.txt).
+  if constexpr (DYN) {
+    const uint32_t waveStart = (uint32_t)wave * (slots * 64);
+    const uint32_t mine = n > waveStart ? n - waveStart : 0u;
+    const uint32_t waveSlots = 4u * ((mine + 255u) / 256u);
+    slots = waveSlots < slots ? waveSlots : slots;
+  }
 
   uint32_t key[KPT];
   uint32_t val[KV ? KPT : 1];
-  LoadStriped<KPT, false, DYN>(keysIn, first, n, n >= slots * THREADS, 0xFFFFFFFFu, key, slots);  // pad: downsweep.slang:81
-  if constexpr (KV) LoadStriped<KPT, false, DYN>(valuesIn, first, n, n >= slots * THREADS, 0u, val, slots);  // pad: downsweep.slang:85
+  // (the "full" shortcut would skip the per-element bound check: only when no wave was shortened)
+  LoadStriped<KPT, false, DYN>(keysIn, first, n, false, 0xFFFFFFFFu, key, slots);  // pad: downsweep.slang:81
+  if constexpr (KV) LoadStriped<KPT, false, DYN>(valuesIn, first, n, false, 0u, val, slots);  // pad: downsweep.slang:85
 
   // SHARED: ranks, then staging slots, two to a register (< TILE <= 65536): keys, values and positions of 32 elements
   // per lane have to fit 128 registers
