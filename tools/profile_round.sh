@@ -15,9 +15,13 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kernel_
 S=$(find $OUT/kernel_stats -name '*kernel_stats.csv' | head -1)
 cp "$S" $OUT/rocprofv3_kernel_stats.csv 2>/dev/null
 python3 tools/kernel_stats.py "$S" --json $OUT/kernel_stats.json > $OUT/kernel_stats.txt 2>&1
-# the same for the passes of a sort one at a time (histogram + 4 passes per sort, by pass index)
-T=$(find $OUT/kernel_stats -name '*kernel_trace.csv' | head -1)
-python3 tools/pass_parity.py "$T" 0 > $OUT/pass_parity_under_bench.txt 2>&1
+# kernel durations by pass index of ten sorts back to back, keys-only and key+value apart (bench.py's run mixes them)
+for mode in keys kv; do
+  rm -rf /tmp/pr_b2b
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/pr_b2b -o t -- $ROOT/tests/native/vrdx_selftest backtoback 25 $mode 10) \
+      2>&1 | grep "back to back" >> $OUT/pass_times_back_to_back.txt
+  python3 tools/pass_parity.py "$(find /tmp/pr_b2b -name '*kernel_trace.csv' | head -1)" 1 >> $OUT/pass_times_back_to_back.txt 2>&1
+done
 # 3. PMC passes (separate runs, counters only + kernel trace)
 (cd tools/probes && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 pmc_calibrate.hip -I$ROOT/include -L$ROOT/vulkan_radix_sort_amd -lvrdx_hip \
     -Wl,-rpath,$ROOT/vulkan_radix_sort_amd -o /tmp/pmc_calibrate) 2> $OUT/pmc_build.err
