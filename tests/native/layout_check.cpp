@@ -47,6 +47,20 @@ int main() {
             ok = ok && plan.tiles - plan.fullTiles <= cus;
           }
         }
+        // the nine-bit hybrid plan (recorded for 4.2 M < N <= 16.3 M next to passes of 32768-key tiles and more): its
+        // 512 counts and its status rows of 2 KiB per 16384 keys must fit as well, at every alignment
+        if (g.keysPerThread == 32 && cus == 256 && n > 256u * 16384u && ((uint64_t)(n + 511) / 512) * 103 / 100 <= 32768) {
+          const uint64_t tiles9 = vrdx::RoundUp(n, vrdx::Scatter9Slots(n, cus) * 1024u);
+          for (uint32_t address = 0; address < 128; address += 16) {
+            const vrdx::StorageLayout l9 =
+                vrdx::MakeLayout(n, VRDX_STORAGE_ALIGN, plan.tiles, 0x7f0000001000ull + address, plan.blockSums, tiles9);
+            ++cases;
+            ok = ok && vrdx::LayoutFits(l9, n) && l9.top9Offset == 16 + 4096 && l9.clearBytes == 16 + 4096 + 2048;
+            ok = ok && (address + l9.status9Offset) % 128 == 0 && l9.status9Bytes == (tiles9 - 1) * 2048;
+            ok = ok && l9.statusOffset == l9.status9Offset + l9.status9Bytes && l9.statusClearBytes == l9.status9Bytes + l9.regionBytes;
+            ok = ok && (address + l9.inoutOffset) % 128 == 0 && l9.valuesOffset >= l9.inoutOffset + (uint64_t)n * 4;
+          }
+        }
         for (uint32_t address = 0; address < 128; address += 16) {
           if (!allAlignments && address != 0 && address != 32 && address != 112) continue;
           const vrdx::StorageLayout l =

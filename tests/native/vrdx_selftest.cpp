@@ -277,6 +277,8 @@ int Parity(Harness& h, bool quick) {
     sizes.push_back((1u << 23) + (1u << 21) + 77);
     sizes.push_back((1u << 24) + 70001);
     sizes.push_back(3u * (1u << 23) + 200003);
+    // the nine-bit hybrid plan (8.1 M < N <= 16.2 M): the sizes above from 2^23 + 4097 to 2^24 take it; one just below its end
+    sizes.push_back(16200000);
   }
   for (uint32_t n : sizes) {
     for (int seed : {1, 42}) {

@@ -527,6 +527,38 @@ def test_tail_split_tiles_at_their_boundaries(torch_mod, sorter, oracle, n, key_
         check_against_oracle(torch_mod, sorter, oracle, k, values, count=count, indirect=True, max_count=n)
 
 
+@pytest.mark.parametrize("n", [ROUND + 12345, 12_000_001, 16_200_000])
+def test_nine_bit_hybrid_plan_and_its_fallback_at_the_sub_bucket_capacity(torch_mod, sorter, oracle, n):
+    """Sorts of 8.1 M < N <= 16.2 M elements record the nine-bit hybrid plan in front of their four passes: one stable
+    scatter by the top nine bits (scatter9_kernel), then 512 sub-buckets of at most 32768 elements each sorted inside one
+    workgroup; the DEVICE keeps the four passes when a nine-bit value occurs more often than that.  Uniform keys with ONE
+    nine-bit value brought to exactly 32768 occurrences (plan applies: word 1 of the storage says 3) and to 32769 (four
+    passes: it says 2 or stays 0), keys-only and key+value (values = iota: the permutation itself), direct and indirect
+    with a smaller device-side count."""
+    cap = 32768
+    rng = np.random.default_rng(n)
+    iota = np.arange(n, dtype=np.uint32)
+    for heavy in (cap, cap + 1):
+        k = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+        top9 = k >> 23
+        k[top9 == 0x155] ^= np.uint32(1 << 23)                       # nobody has the nine-bit value 0x155 ...
+        where = rng.choice(n, size=heavy, replace=False)
+        k[where] = (k[where] & np.uint32(0x007FFFFF)) | np.uint32(0x155 << 23)   # ... except exactly `heavy` keys
+        assert int(((k >> 23) == 0x155).sum()) == heavy
+        ek, ep, _ = oracle.sort(k, iota)
+        kept = []
+        gk, _ = gpu_sort(torch_mod, sorter, k, storage_out=kept)
+        assert np.array_equal(gk, ek), heavy
+        verdict = int(kept[0][4:8].cpu().numpy().view(np.uint32)[0])
+        assert (verdict == 3) == (heavy == cap), (heavy, verdict)
+        gk, gp = gpu_sort(torch_mod, sorter, k, iota)
+        assert np.array_equal(gk, ek) and np.array_equal(gp, ep), heavy
+        count = n - n // 3
+        ek, ep, _ = oracle.sort(k, iota, count=count)
+        gk, gp = gpu_sort(torch_mod, sorter, k, iota, count=count, indirect=True, max_count=n)
+        assert np.array_equal(gk, ek) and np.array_equal(gp, ep), heavy
+
+
 @pytest.mark.parametrize("n", [ROUND, ROUND + 4097, ROUND + ROUND // 4 + 3, 2 * ROUND - 5, 2 * ROUND])
 def test_block_sums_in_sorts_of_one_round(torch_mod, sorter, oracle, n):
     """Sorts of ONE round of 64 ... 256 tiles of 32768 keys and more on the four-pass plan take their prefixes from block
@@ -534,8 +566,15 @@ def test_block_sums_in_sorts_of_one_round(torch_mod, sorter, oracle, n):
     key+value), the two-sub-tile kernel's even-split tiles from 129 tiles up to 256 full ones; direct and indirect with
     a smaller count (whole blocks of 32 tiles past the count).  Values = iota: the permutation itself."""
     k, _ = oracle.generate(17, n, 32)
+    # (uniform keys of these sizes would take the nine-bit hybrid plan recorded in front of the passes: one nine-bit value
+    # occurring 40000 times sends the sort down its four passes, which is where the block sums are)
+    k[:: max(1, n // 40000)][:40000] = (k[:: max(1, n // 40000)][:40000] & np.uint32(0x007FFFFF)) | np.uint32(0x0AB << 23)
     iota = np.arange(n, dtype=np.uint32)
-    check_against_oracle(torch_mod, sorter, oracle, k)
+    kept = []
+    ek, _, _ = oracle.sort(k)
+    gk, _ = gpu_sort(torch_mod, sorter, k, storage_out=kept)
+    assert np.array_equal(gk, ek)
+    assert int(kept[0][4:8].cpu().numpy().view(np.uint32)[0]) != 3   # the four passes ran, not the nine-bit plan
     check_against_oracle(torch_mod, sorter, oracle, k, iota)
     count = n - n // 3 - 7
     check_against_oracle(torch_mod, sorter, oracle, k, count=count, indirect=True, max_count=n)

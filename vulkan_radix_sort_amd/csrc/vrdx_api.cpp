@@ -98,7 +98,9 @@ int ForcedConfigIndex() {
 //    (1, 2], just below 4 or 6.
 enum : int { kCfg1024x8 = 0, kCfg1024x16 = 1, kCfg1024x32 = 2, kCfg1024x32x2 = 3 };
 
-int ConfigIndex(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount, bool atomicRank) {
+// nineBit: the nine-bit hybrid plan is recorded in front of the passes, which are then only the fallback for skewed keys;
+// its status rows take half of the reference's partition-histogram area, so the passes must not take tiles of 16384.
+int ConfigIndex(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount, bool atomicRank, bool nineBit = false) {
   const int forced = ForcedConfigIndex();
   // (the two-sub-tile kernel is keys-only: a key+value sort under a forced 1024x32x2 takes 1024x32)
   if (forced >= 0) return forced == kCfg1024x32x2 && (keyValue || !atomicRank) ? kCfg1024x32 : forced;
@@ -109,7 +111,7 @@ int ConfigIndex(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount
     // just past one round of 32768-element tiles, two workgroups of 16384 per CU fill the second round's gap
     // (1.2-2.6 % at 1.07 <= f <= 1.32, profiles/r03_sweep_by_geometry.txt; still so with the tail split of round 4,
     // profiles/r04_tail_split_kv.txt)
-    if (f > 1.0 && f <= 1.35) return kCfg1024x16;
+    if (f > 1.0 && f <= 1.35 && !nineBit) return kCfg1024x16;
     return kCfg1024x32;
   }
   if (f <= 0.125) return kCfg1024x8;
@@ -193,6 +195,27 @@ uint32_t HybridCapacity(bool atomicRank, uint32_t elementCount) {
   if (need <= 16384u) return 16384u;
   if (need <= largest) return largest;
   return needLast <= largest ? largest : 0u;
+}
+
+// The nine-bit hybrid plan (scatter9_kernel + 512 sub-bucket sorts, vrdx_kernels.hip) carries the two-trip plan past the
+// point where a bucket of the top byte no longer fits a workgroup: recorded -- in front of the passes, which return on its
+// verdict -- for sorts beyond the eight-bit plan's reach whose mean sub-bucket N / 512 leaves 3 % of room in 32768
+// (8.1 M < N <= 16.2 M elements; one-atomic ranking only, like the 32768-element buckets).  Returns the capacity or 0.
+// Measured (profiles/r04_nine_bit_plan.txt): key+value 0.80-0.83 x the time of the four passes over the whole range
+// (58-76 instead of 48-62 GItems/s), keys-only 0.90-0.95 x (its scatter by nine bits is no match for a pass of the
+// two-sub-tile kernel -- 43 against 29 us at 12.6 M keys -- and the four returning passes cost 4.4 us each).
+// VRDX_HYBRID=0 and a forced tile geometry switch it off with the eight-bit plan, VRDX_HYBRID9=0 alone.
+uint32_t Hybrid9Capacity(bool atomicRank, uint32_t elementCount, uint32_t hybridCap) {
+  static const bool enabled = [] {
+    const char* all = std::getenv("VRDX_HYBRID");
+    const char* nine = std::getenv("VRDX_HYBRID9");
+    return (all == nullptr || all[0] != '0') && (nine == nullptr || nine[0] != '0');
+  }();
+  if (!enabled || !atomicRank || hybridCap != 0 || elementCount <= 256u * 16384u) return 0;
+  static const int knobLast = TuningKnob("VRDX_HYBRID_HEADROOM_LAST");
+  const uint64_t mean = (elementCount + 511u) / 512u;
+  const uint64_t need = mean * (uint64_t)(knobLast > 0 ? knobLast : 103) / 100u;
+  return need <= 32768u ? 32768u : 0u;
 }
 
 bool SmallSortEnabled() {
@@ -292,17 +315,28 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   } deviceScope(sorter->device);
 
   const bool atomicRank = sorter->atomicRank.load(std::memory_order_relaxed);  // one answer for the whole sort
-  const int configIndex = ConfigIndex(sorter, keyValue, elementCount, atomicRank);
-  const vrdx::TilePlan tilePlan = PlanTiles(sorter, configIndex, keyValue, elementCount, atomicRank);
   const uint32_t hybridCap = ForcedConfigIndex() < 0 ? HybridCapacity(atomicRank, elementCount) : 0u;
+  uint32_t cap9 = ForcedConfigIndex() < 0 ? Hybrid9Capacity(atomicRank, elementCount, hybridCap) : 0u;
+  const int configIndex = ConfigIndex(sorter, keyValue, elementCount, atomicRank, cap9 != 0);
+  const vrdx::TilePlan tilePlan = PlanTiles(sorter, configIndex, keyValue, elementCount, atomicRank);
   // Block sums instead of the look-back chain: sorts of one round (PlanTiles) on the four-pass plan -- with a hybrid
   // plan recorded, launch 0 may rank by another byte than its pass index, which the block-sum form does not look up.
   // VRDX_BLOCK_SUMS=0 keeps the classic look-back (measurements).
   static const int blockSumsKnob = TuningKnob("VRDX_BLOCK_SUMS");
   const bool blockSums = tilePlan.blockSums && hybridCap == 0 && blockSumsKnob != 0;
   uint8_t* const storage = BufferAddress(storageBuffer, storageOffset);
-  const vrdx::StorageLayout layout = vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, tilePlan.tiles,
-                                                      (uint64_t)reinterpret_cast<uintptr_t>(storage), blockSums);
+  const uint32_t slots9 = vrdx::Scatter9Slots(elementCount, (uint32_t)sorter->computeUnits);
+  uint32_t tiles9 = cap9 != 0 ? vrdx::RoundUp(elementCount, slots9 * 1024u) : 0u;
+  vrdx::StorageLayout layout = vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, tilePlan.tiles,
+                                                (uint64_t)reinterpret_cast<uintptr_t>(storage), blockSums, tiles9);
+  if (cap9 != 0 && !vrdx::LayoutFits(layout, elementCount)) {
+    // (cannot happen for the sizes Hybrid9Capacity admits -- tests/native/layout_check.cpp sweeps them -- but the
+    // storage is the caller's: without the nine-bit plan's 2 KiB rows the layout fits for every N)
+    cap9 = 0;
+    tiles9 = 0;
+    layout = vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, tilePlan.tiles,
+                              (uint64_t)reinterpret_cast<uintptr_t>(storage), blockSums, 0);
+  }
   uint32_t* const keys = reinterpret_cast<uint32_t*>(BufferAddress(keysBuffer, keysOffset));
   uint32_t* const values =
       keyValue ? reinterpret_cast<uint32_t*>(BufferAddress(valuesBuffer, valuesOffset)) : nullptr;
@@ -344,6 +378,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   Stamp(pool, query + 1, stream);
 
   uint32_t* const globalHistogram = reinterpret_cast<uint32_t*>(storage + layout.histogramOffset);
+  uint32_t* const top9Table = cap9 != 0 ? reinterpret_cast<uint32_t*>(storage + layout.top9Offset) : nullptr;
   uint32_t* const status = reinterpret_cast<uint32_t*>(storage + layout.statusOffset);
   uint32_t* const tickets = reinterpret_cast<uint32_t*>(storage + layout.ticketOffset);
   uint32_t* const failure = reinterpret_cast<uint32_t*>(storage + layout.failureOffset);
@@ -367,8 +402,8 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     static const int forcedGrid = TuningKnob("VRDX_HIST_GRID");  // tools/hist_grid.sh
     if (forcedGrid > 0) grid = (uint32_t)forcedGrid;
     EnqueueCheck(sorter, "histogram_kernel",
-                 vrdx::LaunchHistogram(stream, grid, keys, elementCount, countPtr, globalHistogram, tickets, status,
-                                       (uint32_t)layout.statusClearBytes));
+                 vrdx::LaunchHistogram(stream, grid, keys, elementCount, countPtr, globalHistogram, tickets,
+                                       storage + layout.status9Offset, (uint32_t)layout.statusClearBytes, top9Table));
   }
 
   const uint32_t tiles = tilePlan.tiles;
@@ -379,6 +414,43 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   bool earlyValues = true;
   static const int forcedEarly = TuningKnob("VRDX_KV_EARLY_VALUES");  // 0 | 1: tuning/testing
   if (forcedEarly >= 0) earlyValues = forcedEarly != 0;
+  // The nine-bit hybrid plan, recorded in front of the passes: one scatter by the top nine bits, then 512 sub-bucket
+  // sorts.  Both launches decide on the device whether the plan applies (no nine-bit value occurs more than cap9 times);
+  // if it does, every launch of the four passes returns on the verdict word, if not, these two return and the passes
+  // run as if nothing had been recorded in front of them.  (Timestamps: both fall into the "upsweep" slot of pass 0.)
+  vrdx::OnesweepArgs nine;
+  std::memset(&nine, 0, sizeof(nine));
+  if (cap9 != 0) {
+    nine.keysCaller = keys;
+    nine.keysScratch = keysScratch;
+    nine.valuesCaller = keyValue ? values : nullptr;
+    nine.valuesScratch = keyValue ? valuesScratch : nullptr;
+    nine.maxCount = elementCount;
+    nine.countPtr = countPtr;
+    nine.histogramTable = globalHistogram;
+    nine.statusCur = reinterpret_cast<uint32_t*>(storage + layout.status9Offset);
+    nine.ticketCur = tickets + 2;  // its own ticket word in the ticket line (zeroed by the histogram kernel)
+    nine.failure = failure;
+    nine.stickyFailure = sorter->stickyStatus;
+    nine.spinLimit = vrdx::kSpinLimit;
+    nine.planWord = reinterpret_cast<uint32_t*>(storage + VRDX_OFF_PLAN);
+    nine.cap9 = cap9;
+    nine.top9Table = top9Table;
+    nine.slots = slots9;
+    EnqueueCheck(sorter, "scatter9_kernel", vrdx::LaunchScatter9(stream, tiles9, keyValue, nine));
+    vrdx::BucketSortArgs b;
+    b.keysScratch = keysScratch;
+    b.keysCaller = keys;
+    b.valuesScratch = keyValue ? valuesScratch : nullptr;
+    b.valuesCaller = keyValue ? values : nullptr;
+    b.maxCount = elementCount;
+    b.countPtr = countPtr;
+    b.histogramTable = globalHistogram;
+    b.hybridCap = cap9;
+    b.planWord = reinterpret_cast<const uint32_t*>(storage + VRDX_OFF_PLAN);
+    b.top9Table = top9Table;
+    EnqueueCheck(sorter, "bucket_sort_kernel (nine-bit)", vrdx::LaunchBucketSort9(stream, keyValue, b));
+  }
   for (uint32_t pass = 0; pass < VRDX_PASSES; ++pass) {
     // "upsweep" of this pass: the fused histogram kernel for pass 0, nothing for the others -- the same
     // point of the stream as the previous pass's "downsweep" stamp
@@ -397,6 +469,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
       b.histogramTable = globalHistogram;
       b.hybridCap = hybridCap;
       b.planWord = reinterpret_cast<const uint32_t*>(storage + VRDX_OFF_PLAN);
+      b.top9Table = nullptr;
       EnqueueCheck(sorter, "bucket_sort_kernel", vrdx::LaunchBucketSort(stream, keyValue, atomicRank, b));
       Stamp(pool, query + 2 + 3 * pass + 0, stream);
     } else {
@@ -439,6 +512,8 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     if (testSpinLimit >= 0) args.spinLimit = (uint32_t)testSpinLimit;
 #endif
     args.earlyValues = earlyValues ? 1u : 0u;
+    args.cap9 = cap9;
+    args.top9Table = top9Table;
     args.slots = tilePlan.slots;
     args.fullTiles = tilePlan.fullTiles;
     args.tailSlots = tilePlan.tailSlots;
@@ -741,8 +816,8 @@ const char* vrdxHipVersionString(void) {
   static char text[160];
   VrdxSorter_T nominal;  // an MI355X: 256 CUs, lane-ordered LDS atomics
   nominal.computeUnits = 256;
-  const vrdx::TileConfig& k = vrdx::kTileConfigs[ConfigIndex(&nominal, false, 1u << 25, true)];
-  const vrdx::TileConfig& kv = vrdx::kTileConfigs[ConfigIndex(&nominal, true, 1u << 25, true)];
+  const vrdx::TileConfig& k = vrdx::kTileConfigs[ConfigIndex(&nominal, false, 1u << 25, true, false)];
+  const vrdx::TileConfig& kv = vrdx::kTileConfigs[ConfigIndex(&nominal, true, 1u << 25, true, false)];
   char kName[32], kvName[32];
   ConfigName(k, kName, sizeof(kName));
   ConfigName(kv, kvName, sizeof(kvName));

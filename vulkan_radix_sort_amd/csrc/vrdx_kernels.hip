@@ -328,6 +328,22 @@ __device__ __forceinline__ uint32_t BlockExclusiveScan256(uint32_t v, uint32_t* 
   return x - v + add;
 }
 
+// The same over threads 0..511 (8 waves): the 512 sub-buckets of the nine-bit hybrid plan.
+__device__ __forceinline__ uint32_t BlockExclusiveScan512(uint32_t v, uint32_t* scratch8, int tid) {
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const uint32_t x = WaveInclusiveScan(v);
+  if (wave < 8 && lane == 63) scratch8[wave] = x;
+  LdsBarrier();
+  uint32_t add = 0;
+  if (wave < 8) {
+#pragma unroll
+    for (int w = 0; w < 7; ++w)
+      if (w < wave) add += scratch8[w];
+  }
+  return x - v + add;
+}
+
 // ---------------------------------------------------------------------------------------------
 // histogram: all four digit histograms in one pass over the keys
 // ---------------------------------------------------------------------------------------------
@@ -365,27 +381,36 @@ __device__ __forceinline__ void HistFetch(const u32x4* keys4, uint32_t group, ui
 // and the two tickets: nothing reads them before pass 0, which starts when this kernel has drained.  Before round 4
 // the fill in front of the histogram cleared region 0 as well -- 1-2 MiB at N = 2^25, a 4.4 us fill kernel on the
 // critical path of every sort where 4 KiB (header + table, which the atomics below need zeroed) take 2 us.
-template <uint32_t COPIES>
+// TOP9 (sorts that record the nine-bit hybrid plan, vrdx_api.cpp): instead of byte 3 the kernel counts the TOP NINE BITS
+// of the keys -- 512 bins x COPIES9 replicas behind the three byte tables, still four atomics per key -- and leaves
+// both the 512 counts (top9Table) and their pair sums, which are the byte-3 counts, in the global tables.
+template <uint32_t COPIES, bool TOP9>
 __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t* __restrict__ keys,
                                                                   uint32_t maxCount,
                                                                   const uint32_t* countPtr,
                                                                   uint32_t* __restrict__ globalHistogram,
                                                                   uint32_t* __restrict__ tickets,
                                                                   u32x4* __restrict__ statusClear,
-                                                                  uint32_t statusVecs) {
+                                                                  uint32_t statusVecs,
+                                                                  uint32_t* __restrict__ top9Table) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  uint32_t* const bins = smem;  // [pass][digit][copy]
+  uint32_t* const bins = smem;  // [pass][digit][copy] (TOP9: three passes, then [512][COPIES9])
+  constexpr uint32_t COPIES9 = COPIES < kHistCopiesTop9 ? COPIES : kHistCopiesTop9;
+  constexpr uint32_t kByteTables = TOP9 ? VRDX_PASSES - 1 : VRDX_PASSES;
+  constexpr uint32_t kBinWords = kByteTables * VRDX_RADIX * COPIES + (TOP9 ? 512u * COPIES9 : 0u);
+  uint32_t* const bins9 = smem + kByteTables * VRDX_RADIX * COPIES;
   const uint32_t tid = threadIdx.x;
-  if (blockIdx.x == 0 && tid < 2) tickets[tid] = 0;  // outside the cleared prefix of the storage (vrdx_layout.h)
+  if (blockIdx.x == 0 && tid < 3) tickets[tid] = 0;  // outside the cleared prefix of the storage (vrdx_layout.h)
   const uint32_t n = ElementCount(maxCount, countPtr);
 
   const uint32_t copy = tid & (COPIES - 1);
   auto count = [&](uint32_t key) {
 #pragma unroll
-    for (uint32_t p = 0; p < VRDX_PASSES; ++p) {
+    for (uint32_t p = 0; p < kByteTables; ++p) {
       const uint32_t d = (key >> (8 * p)) & 0xFFu;
       atomicAdd(&bins[(p * VRDX_RADIX + d) * COPIES + copy], 1u);
     }
+    if constexpr (TOP9) atomicAdd(&bins9[(key >> 23) * COPIES9 + (tid & (COPIES9 - 1))], 1u);
   };
   auto tally = [&](uint32_t group, const u32x4 (&k)[4], uint32_t nvec) {
 #pragma unroll
@@ -414,7 +439,7 @@ __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t*
     // the first two groups' loads fly while the counters are cleared (nvec >= 1 here)
     HistFetch<NT>(keys4, g, tid, nvec, a);
     HistFetch<NT>(keys4, g + step, tid, nvec, b);
-    for (uint32_t i = tid; i < VRDX_PASSES * VRDX_RADIX * COPIES; i += kHistThreads) bins[i] = 0;
+    for (uint32_t i = tid; i < kBinWords; i += kHistThreads) bins[i] = 0;
     LdsBarrier();  // LDS only: the loads in flight are not waited for here
     for (; g < end; g += 2 * step) {
       tally(g, a, nvec);
@@ -425,7 +450,7 @@ __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t*
   };
   const bool streamingInput = VRDX_HIST_NT == 2 || (VRDX_HIST_NT == 1 && n > kHistStreamingLoadsAbove);
   if (nvec == 0) {  // fewer than four keys
-    for (uint32_t i = tid; i < VRDX_PASSES * VRDX_RADIX * COPIES; i += kHistThreads) bins[i] = 0;
+    for (uint32_t i = tid; i < kBinWords; i += kHistThreads) bins[i] = 0;
     LdsBarrier();
   } else if (streamingInput) {
     asm volatile("; non-temporal key loads" ::: "memory");  // keeps the two loops apart (see LoadTile)
@@ -439,12 +464,27 @@ __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t*
     statusClear[i] = u32x4{0u, 0u, 0u, 0u};
   __syncthreads();
 
-  for (uint32_t b = tid; b < VRDX_PASSES * VRDX_RADIX; b += kHistThreads) {
+  for (uint32_t b = tid; b < kByteTables * VRDX_RADIX; b += kHistThreads) {
     uint32_t sum = 0;
     // rotated by the lane so that the lanes of one read do not all hit copy c's bank
 #pragma unroll
     for (uint32_t c = 0; c < COPIES; ++c) sum += bins[b * COPIES + ((c + tid) & (COPIES - 1))];
     if (sum != 0) atomicAdd(&globalHistogram[b], sum);
+  }
+  if constexpr (TOP9) {
+    static_assert(kHistThreads == 1024, "threads 768..1023 and 0..255 take the nine-bit bins");
+    // threads 768..1023 are free in the loop above (3 x 256 bins): they and threads 0..255 take the 512 nine-bit bins
+    const uint32_t b9 = tid >= 768u ? tid - 768u : (tid < 256u ? tid + 256u : 512u);
+    if (b9 < 512u) {
+      uint32_t sum = 0;
+#pragma unroll
+      for (uint32_t c = 0; c < COPIES9; ++c) sum += bins9[b9 * COPIES9 + ((c + tid) & (COPIES9 - 1))];
+      if (sum != 0) atomicAdd(&top9Table[b9], sum);
+      // byte 3 = the nine bits without the last: the pair sum, added by the even lane alone -- two lanes of ONE atomic
+      // instruction on the same address cost this kernel 57 us (77 instead of 21 at 12.6 M keys, measured)
+      const uint32_t pair = sum + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0xB1, 0xf, 0xf, true);  // quad_perm:[1,0,3,2]
+      if ((b9 & 1u) == 0 && pair != 0) atomicAdd(&globalHistogram[(VRDX_PASSES - 1) * VRDX_RADIX + (b9 >> 1)], pair);
+    }
   }
 }
 
@@ -518,23 +558,24 @@ __device__ __forceinline__ void StoreQuad(uint32_t* out, uint32_t index, u32x4 q
   }
 }
 
-template <int THREADS>
+// RADIX: digits per status row (256; 512 in the nine-bit scatter: two groups of 512 threads then).
+template <int THREADS, int RADIX = 256>
 __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t tile, int tid, uint32_t* lds,
                                              uint32_t* failure, uint32_t* stickyFailure, uint32_t spinLimit,
                                              uint32_t* traceTripsRows) {
-  constexpr int GROUPS = THREADS / 256;
+  constexpr int GROUPS = THREADS / RADIX;
   constexpr int W = kLookBackWindow;
   int32_t* const pos = reinterpret_cast<int32_t*>(lds);
-  uint32_t* const sum = lds + 256;
-  uint32_t* const info = sum + GROUPS * 256;
-  const int g = tid >> 8;
-  const int d = tid & 255;
+  uint32_t* const sum = lds + RADIX;
+  uint32_t* const info = sum + GROUPS * RADIX;
+  const int g = tid / RADIX;
+  const int d = tid % RADIX;
 
   uint32_t exclusive = 0;
   uint32_t spins = 0;
   uint32_t traceTrips = 0, traceRows = 0;  // thread 0 only, reported to tools/trace.sh builds
   bool done = g != 0;  // only group 0 owns the per-digit state
-  uint32_t* const vote = info + GROUPS * 256;  // [2]: "some digit is still walking", by trip parity
+  uint32_t* const vote = info + GROUPS * RADIX;  // [2]: "some digit is still walking", by trip parity
   if (g == 0) pos[d] = (int32_t)tile - 1;
   if (tid < 2) vote[tid] = 0;
   LdsBarrier();
@@ -547,7 +588,7 @@ __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t ti
 #pragma unroll
       for (int k = 0; k < W; ++k) {
         const int32_t row = first - k;
-        v[k] = row >= 0 ? LoadStatus(&status[(uint32_t)row * VRDX_RADIX + d])
+        v[k] = row >= 0 ? LoadStatus(&status[(uint32_t)row * (uint32_t)RADIX + d])
                         : (VRDX_FLAG_INCLUSIVE << VRDX_FLAG_SHIFT);
       }
       uint32_t partial = 0, consumed = 0, hit = 0;
@@ -565,16 +606,16 @@ __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t ti
           }
         }
       }
-      sum[g * 256 + d] = partial;
-      info[g * 256 + d] = consumed | (hit << 8);
+      sum[g * RADIX + d] = partial;
+      info[g * RADIX + d] = consumed | (hit << 8);
     }
     LdsBarrier();
     if (g == 0 && !done) {
       uint32_t advance = 0;
 #pragma unroll
       for (int gg = 0; gg < GROUPS; ++gg) {
-        const uint32_t in = info[gg * 256 + d];
-        exclusive += sum[gg * 256 + d];
+        const uint32_t in = info[gg * RADIX + d];
+        exclusive += sum[gg * RADIX + d];
         advance += in & 0xFFu;
         if (in >> 8) {
           done = true;
@@ -730,7 +771,8 @@ __device__ __forceinline__ void RankBallot(const uint32_t (&key)[KPT], uint32_t 
 }
 
 // PACKED: ranks (< 64 * KPT <= 65536) are written two to a register, out[i / 2] bits 16*(i % 2).
-template <int KPT, bool PACKED, bool DYN = false>
+// MASK: the digit is (key >> shift) & MASK -- 0xFF everywhere except the 512-way scatter of the nine-bit hybrid plan.
+template <int KPT, bool PACKED, bool DYN = false, uint32_t MASK = 0xFFu>
 __device__ __forceinline__ void RankAtomic(const uint32_t (&key)[KPT], uint32_t shift, uint32_t* myHist,
                                            int lane, uint32_t (&out)[PACKED ? KPT / 2 : KPT], uint32_t slots = KPT) {
   // eight slots at a time: eight atomics in flight, eight wave-uniform flags live (more would
@@ -749,14 +791,14 @@ __device__ __forceinline__ void RankAtomic(const uint32_t (&key)[KPT], uint32_t 
   for (int base = 0; base < KPT; base += CHUNK) {
     if (DYN && (uint32_t)base >= slots) break;
     uint32_t r[CHUNK];
-    const uint32_t probe = (key[base] >> shift) & 0xFFu;
+    const uint32_t probe = (key[base] >> shift) & MASK;
     const bool watch = __popcll(__ballot(probe != (uint32_t)__builtin_amdgcn_readfirstlane(probe))) <= 48;  // wave-uniform
     if (watch) {
       bool uniform[CHUNK];
 #pragma unroll
       for (int c = 0; c < CHUNK; ++c) {
         const int i = base + c;
-        const uint32_t d = (key[i] >> shift) & 0xFFu;
+        const uint32_t d = (key[i] >> shift) & MASK;
         const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
         const uint64_t others = __ballot(d != d0);
         uniform[c] = others == 0ull;  // wave-uniform
@@ -794,7 +836,7 @@ __device__ __forceinline__ void RankAtomic(const uint32_t (&key)[KPT], uint32_t 
     } else {
 #pragma unroll
       for (int c = 0; c < CHUNK; ++c)
-        r[c] = __hip_atomic_fetch_add(&myHist[(key[base + c] >> shift) & 0xFFu], 1u, __ATOMIC_RELAXED,
+        r[c] = __hip_atomic_fetch_add(&myHist[(key[base + c] >> shift) & MASK], 1u, __ATOMIC_RELAXED,
                                       __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 #pragma unroll
@@ -836,7 +878,7 @@ __device__ __forceinline__ uint32_t StagingSlot(uint32_t p) {
 // array cannot be reordered by the compiler, so a read-store-read-store source order costs a full
 // LDS round trip per key).  PACKED ranks come two to a register; with KEEP the physical slots are
 // returned packed the same way (key+value stages the values through them).
-template <int KPT, uint32_t STAGE, bool PACKED, bool KEEP, bool DYN = false>
+template <int KPT, uint32_t STAGE, bool PACKED, bool KEEP, bool DYN = false, uint32_t MASK = 0xFFu>
 __device__ __forceinline__ void RegroupKeys(const uint32_t (&key)[KPT], const uint32_t (&rank)[PACKED ? KPT / 2 : KPT],
                                             uint32_t shift, const uint32_t* waveBase, uint32_t* sorted,
                                             uint32_t (&slots)[KEEP ? KPT / 2 : 1], uint32_t slotCount = KPT) {
@@ -846,7 +888,7 @@ __device__ __forceinline__ void RegroupKeys(const uint32_t (&key)[KPT], const ui
     if (DYN && (uint32_t)base >= slotCount) break;
     uint32_t p[CHUNK];
 #pragma unroll
-    for (int c = 0; c < CHUNK; ++c) p[c] = waveBase[(key[base + c] >> shift) & 0xFFu];
+    for (int c = 0; c < CHUNK; ++c) p[c] = waveBase[(key[base + c] >> shift) & MASK];
 #pragma unroll
     for (int c = 0; c < CHUNK; ++c) {
       const int i = base + c;
@@ -1062,6 +1104,8 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   if constexpr (kVerdictWord) {
     if (a.hybridCap != 0 && a.pass != 0 && *a.planWord == 1u) return;
   }
+  // the nine-bit plan (scatter9_kernel, recorded in front of launch 0) has taken the sort: nothing left for the passes
+  if (a.cap9 != 0 && *a.planWord == 3u) return;
 
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   uint32_t key[KPT];
@@ -1315,6 +1359,7 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
 #endif
   VRDX_STAMP(0);
 
+  if (a.cap9 != 0 && *a.planWord == 3u) return;  // the nine-bit plan has taken the sort (see onesweep_kernel)
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   const PassCounts<THREADS> passCounts = LoadPassCounts<THREADS>(a.histogramTable, tid);
   if (tid == 0) misc[0] = atomicAdd(a.ticketCur, 1u);
@@ -1491,6 +1536,181 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
     for (int i = 0; i < 8; ++i) a.trace[(size_t)tile * 8 + i] = stamps[i];
   }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// scatter9_kernel: first half of the NINE-BIT hybrid plan -- one stable scatter by the top nine bits
+// ---------------------------------------------------------------------------------------------
+// The hybrid plan of mid-size sorts (PassPlan above) ends where a bucket of the top BYTE no longer fits one workgroup's
+// LDS: 256 x 32768 elements.  Twice as many buckets carry it twice as far: this kernel scatters by the top NINE bits
+// (512 sub-buckets; caller -> scratch), bucket_sort_kernel<..., 512> then sorts every sub-bucket by its low 24 bits inside
+// one workgroup (scratch -> caller), and the ordinary launches 0..3 of the sort return on the verdict word.  The plan
+// applies iff no nine-bit value occurs more than a.cap9 (= 32768) times -- every workgroup decides that alike from the
+// 512 counts the histogram kernel left in a.top9Table; otherwise this launch returns without touching anything and the
+// sort runs its four passes as if the plan had never been recorded.
+//
+// It is onesweep_kernel with 512 digits, written out: 1024 threads x up to 32 keys (a.slots slots of 64 keys per wave,
+// a multiple of four: the host cuts the sort into equal tiles, two rounds of them, Scatter9Slots in vrdx_api.cpp),
+// wave-private counters 16 x 512 words, one status row of 512 words per tile in a status region of its own, look-back by
+// two groups of 512 threads.  One-atomic ranking only (like the 32768-element buckets).
+// LDS: staging 128 KiB | counters 32 KiB = exactly the CU's 160 KiB: scan scratch, ticket and verdict flags live in the
+// staging buffer before the regroup, look-back scratch and the 512 scatter offsets in the counters after it.
+// (First version: tiles of 16384 keys, 96 KiB: 49.6 us at 12.6 M keys against 28.8 us for a pass of the two-sub-tile
+// kernel, which ate the plan's gain for keys-only sorts; profiles/r04_nine_bit_plan.txt.)
+constexpr int kScatter9Threads = 1024;
+constexpr int kScatter9Kpt = 32;
+constexpr uint32_t kScatter9Tile = kScatter9Threads * kScatter9Kpt;
+constexpr uint32_t kTop9 = 512;
+constexpr uint32_t kTop9Shift = 23;
+constexpr size_t kScatter9LdsWords = (size_t)kScatter9Tile + (size_t)(kScatter9Threads / 64) * kTop9;
+static_assert(kScatter9LdsWords * 4 <= 160 * 1024, "fits the CU's LDS");
+
+template <bool KV>
+__global__ __launch_bounds__(kScatter9Threads) void scatter9_kernel(OnesweepArgs a) {
+  constexpr int THREADS = kScatter9Threads;
+  constexpr int KPT = kScatter9Kpt;
+  constexpr int WAVES = THREADS / 64;
+  constexpr uint32_t TILE = kScatter9Tile;
+  constexpr uint32_t MASK = kTop9 - 1;
+  constexpr bool DYN = true;
+  static_assert(WAVES * kTop9 >= kTop9 * (1 + 2 * (THREADS / kTop9)) + 2 + kTop9, "look-back scratch and offsets alias the counters");
+
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  uint32_t* const sorted = smem;                               // TILE: keys (then values) regrouped by digit
+  uint32_t* const waveHist = smem + TILE;                      // WAVES x 512, then look-back scratch
+  uint32_t* const tileOffset = waveHist + (WAVES - 1) * kTop9;  // 512: global base - tile-local base (after the regroup)
+  uint32_t* const scanScratch = smem;                          // 16 (before the regroup)
+  uint32_t* const misc = smem + 16;                            // [0] ticket, [1..16] "over capacity" by wave
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+
+  // the verdict, the same in every workgroup: does any nine-bit value occur more than cap9 times?
+  const uint32_t n = ElementCount(a.maxCount, a.countPtr);
+  const uint32_t bucketCount = tid < (int)kTop9 ? a.top9Table[tid] : 0u;
+  const uint64_t over = __ballot(bucketCount > a.cap9);
+  if (lane == 0) misc[1 + wave] = over != 0ull ? 1u : 0u;
+  for (int i = tid; i < WAVES * (int)kTop9; i += THREADS) waveHist[i] = 0;
+  LdsBarrier();
+  uint32_t anyOver = 0;
+#pragma unroll
+  for (int w = 0; w < WAVES; ++w) anyOver |= misc[1 + w];
+  if (anyOver != 0 || n == 0) return;  // uniform: the plan does not apply, the four passes run
+  LdsBarrier();  // misc is read; the ticket goes into it next
+  if (tid == 0) misc[0] = atomicAdd(a.ticketCur, 1u);  // a ticket word of this launch's own (the passes have theirs)
+  LdsBarrier();
+  const uint32_t tile = misc[0];
+  if (tile == 0 && tid == 0) *a.planWord = 3u;  // for the launches behind this one: nothing left to do but the buckets
+  const uint32_t slots = a.slots;               // per wave, a multiple of four, <= KPT
+  const uint32_t frame = slots * THREADS;
+  const uint32_t tiles = (n + frame - 1) / frame;
+  if (tile >= tiles) return;
+  const bool lastTile = tile == tiles - 1;
+  const uint32_t tileStart = tile * frame;
+  const uint32_t valid = (n - tileStart) < frame ? (n - tileStart) : frame;
+  const uint32_t tileEnd = tileStart + valid;
+  const uint32_t loadBase = tileStart + wave * (slots * 64) + lane;
+
+  uint32_t key[KPT];
+  uint32_t val[KV ? KPT : 1];
+  LoadStriped<KPT, false, DYN>(a.keysCaller, loadBase, tileEnd, valid == frame, 0xFFFFFFFFu, key, slots);  // pad: downsweep.slang:81
+  constexpr bool PACKED = true;  // ranks and positions < TILE <= 65536, two to a register
+  uint32_t rank[KPT / 2];
+  RankAtomic<KPT, PACKED, DYN, MASK>(key, kTop9Shift, waveHist + wave * kTop9, lane, rank, slots);
+  ForgetDerivedValues<KPT>(key);
+  LdsBarrier();
+
+  // tile histogram, aggregate, tile-local offsets
+  uint32_t count = 0;
+  if (tid < (int)kTop9) {
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) count += waveHist[w * kTop9 + tid];
+    if (tile != 0 && !lastTile)
+      StoreStatus(&a.statusCur[tile * kTop9 + tid], (VRDX_FLAG_AGGREGATE << VRDX_FLAG_SHIFT) | count);
+  }
+  const uint32_t tileExclusive = BlockExclusiveScan512(tid < (int)kTop9 ? count : 0u, scanScratch, tid);
+  uint32_t exclusive = 0;
+  if (tile == 0) exclusive = BlockExclusiveScan512(bucketCount, scanScratch + 8, tid);  // the global base of every sub-bucket
+  if (tid < (int)kTop9) {
+    uint32_t run = tileExclusive;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+      const uint32_t c = waveHist[w * kTop9 + tid];
+      waveHist[w * kTop9 + tid] = run;
+      run += c;
+    }
+  }
+  LdsBarrier();
+
+  uint32_t packedPos[KV ? KPT / 2 : 1];
+  RegroupKeys<KPT, TILE, PACKED, KV, DYN, MASK>(key, rank, kTop9Shift, waveHist + wave * kTop9, sorted, packedPos, slots);
+  LdsBarrier();  // waveHist is dead from here on
+
+  if (tile != 0)
+    exclusive = LookBack<THREADS, (int)kTop9>(a.statusCur, tile, tid, waveHist, a.failure, a.stickyFailure, a.spinLimit, nullptr);
+  if (tid < (int)kTop9) {
+    if (!lastTile)
+      StoreStatus(&a.statusCur[tile * kTop9 + tid],
+                  (VRDX_FLAG_INCLUSIVE << VRDX_FLAG_SHIFT) | ((exclusive + count) & VRDX_VALUE_MASK));
+    tileOffset[tid] = exclusive - tileExclusive;
+  }
+  LdsBarrier();
+  // key+value: the values are fetched now (late, like the split forms of onesweep_kernel: early they would be live across
+  // the ranking and the regroup of 32 keys per lane) and land while the keys are scattered
+  if constexpr (KV) LoadStriped<KPT, false, DYN>(a.valuesCaller, loadBase, tileEnd, valid == frame, 0u, val, slots);  // pad: downsweep.slang:85
+
+  // scatter: four consecutive staging words per lane; whole single-digit quads as one 16-byte store, the others word by
+  // word; four quads per batch (reads, then digits and offsets, then stores)
+  constexpr int QUADS = KPT / 4;
+  constexpr int B = 4;
+  uint32_t quadDigits[KV ? QUADS : 1][2];  // key+value: the four digits of every quad, for the value phase
+  auto scatterQuads = [&](uint32_t* out, bool keysPhase) {
+#pragma unroll
+    for (int j0 = 0; j0 < QUADS; j0 += B) {
+      if (4u * (uint32_t)j0 * THREADS >= valid) break;  // batches of quads beyond the tile's keys are not read at all
+      u32x4 w4[B];
+#pragma unroll
+      for (int b = 0; b < B; ++b) w4[b] = *reinterpret_cast<const u32x4*>(&sorted[4u * (tid + (j0 + b) * THREADS)]);
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const int j = j0 + b;
+        const uint32_t p = StagingSlot<TILE>(4u * (tid + j * THREADS));  // involution: the sorted position of the quad
+        uint32_t d[4];
+        if (keysPhase) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) d[c] = (w4[b][c] >> kTop9Shift) & MASK;
+          if constexpr (KV) {
+            quadDigits[j][0] = d[0] | (d[1] << 16);
+            quadDigits[j][1] = d[2] | (d[3] << 16);
+          }
+        } else {
+          d[0] = quadDigits[KV ? j : 0][0] & 0xFFFFu;
+          d[1] = quadDigits[KV ? j : 0][0] >> 16;
+          d[2] = quadDigits[KV ? j : 0][1] & 0xFFFFu;
+          d[3] = quadDigits[KV ? j : 0][1] >> 16;
+        }
+        if (p + 3 < valid && d[0] == d[3]) {
+          StoreQuad(out, tileOffset[d[0]] + p, w4[b]);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (p + c < valid) StoreWord(out, tileOffset[d[c]] + p + c, w4[b][c]);
+        }
+      }
+    }
+  };
+  scatterQuads(a.keysScratch, true);
+  if constexpr (KV) {
+    LdsBarrier();  // every key has left the staging buffer
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      if (i % 4 == 0 && (uint32_t)i >= slots) break;
+      sorted[(packedPos[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
+    }
+    LdsBarrier();
+    scatterQuads(a.valuesScratch, false);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1688,12 +1908,35 @@ __global__ __launch_bounds__(THREADS) void small_sort_kernel(uint32_t* keys, uin
 // derives, from the same table as the pass kernels, whether the hybrid plan applies at all; otherwise this launch has
 // nothing to do (the four-pass plan is running).
 
-template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK>
+// NB = 512: the second half of the NINE-BIT plan (scatter9_kernel above) -- bucket b is the range of the nine-bit value b,
+// counts from a.top9Table; it runs iff scatter9_kernel has written 3 into the verdict word.
+template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK, int NB = 256>
 __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(BucketSortArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  uint32_t* const flags = smem + 16;  // 32
   const int tid = threadIdx.x;
-  if (*a.planWord == 2u) return;  // launch 0's verdict: the four passes are running
+  if constexpr (NB == 512) {
+    static_assert(THREADS >= 512, "one thread per sub-bucket");
+    if (*a.planWord != 3u) return;  // uniform: the nine-bit plan does not apply (or was not reached)
+    const uint32_t count = tid < 512 ? a.top9Table[tid] : 0u;
+    const uint32_t base = BlockExclusiveScan512(count, smem, tid);
+    if (tid == (int)blockIdx.x) {
+      smem[16] = base;
+      smem[17] = count;
+    }
+    LdsBarrier();
+    const uint32_t myBase = (uint32_t)__builtin_amdgcn_readfirstlane((int)smem[16]);
+    const uint32_t myCount = (uint32_t)__builtin_amdgcn_readfirstlane((int)smem[17]);
+    LdsBarrier();  // smem is the sort's from here on
+    if (myCount == 0) return;  // uniform
+    // by the low 24 bits: bit 23 is the same in every key of the sub-bucket
+    SortInWorkgroup<THREADS, KPT, KV, ATOMIC_RANK>(a.keysScratch + myBase, a.keysCaller + myBase,
+                                                   KV ? a.valuesScratch + myBase : nullptr,
+                                                   KV ? a.valuesCaller + myBase : nullptr, myCount, 3u, smem);
+    return;
+  }
+  uint32_t* const flags = smem + 16;  // 32
+  const uint32_t verdict = *a.planWord;
+  if (verdict == 2u || verdict == 3u) return;  // launch 0's verdict: the four passes are running / the nine-bit plan has run
   // the same votes, from the same table, as in the pass kernels: every launch of the sort reaches the same verdict
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   const PassCounts<THREADS> passCounts = LoadPassCounts<THREADS>(a.histogramTable, tid);
@@ -1902,9 +2145,13 @@ hipError_t PrepareKernels(int configIndex) {
     const struct {
       const void* fn;
       uint32_t bytes;
-    } kernels[2] = {
-        {reinterpret_cast<const void*>(&histogram_kernel<kHistCopies>), HistLdsBytes(kHistCopies)},
-        {reinterpret_cast<const void*>(&histogram_kernel<kHistCopiesLarge>), HistLdsBytes(kHistCopiesLarge)},
+    } kernels[6] = {
+        {reinterpret_cast<const void*>(&histogram_kernel<kHistCopies, false>), HistLdsBytes(kHistCopies)},
+        {reinterpret_cast<const void*>(&histogram_kernel<kHistCopiesLarge, false>), HistLdsBytes(kHistCopiesLarge)},
+        {reinterpret_cast<const void*>(&histogram_kernel<kHistCopies, true>), HistTop9LdsBytes(kHistCopies)},
+        {reinterpret_cast<const void*>(&histogram_kernel<kHistCopiesLarge, true>), HistTop9LdsBytes(kHistCopiesLarge)},
+        {reinterpret_cast<const void*>(&scatter9_kernel<false>), (uint32_t)(kScatter9LdsWords * sizeof(uint32_t))},
+        {reinterpret_cast<const void*>(&scatter9_kernel<true>), (uint32_t)(kScatter9LdsWords * sizeof(uint32_t))},
     };
     for (const auto& k : kernels) {
       const hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.bytes);
@@ -2034,6 +2281,13 @@ hipError_t PrepareBucketSort() {
   if (e == hipSuccess)
     e = hipFuncSetAttribute(BucketKernel<32, true, true>(), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(SmallSortLdsWords<1024, 32, true>() * 4));
+  // the nine-bit plan's 512 sub-buckets (same capacity, same ranking)
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_sort_kernel<1024, 32, false, true, 512>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SmallSortLdsWords<1024, 32, false>() * 4));
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_sort_kernel<1024, 32, true, true, 512>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SmallSortLdsWords<1024, 32, true>() * 4));
   return e;
 }
 
@@ -2053,14 +2307,36 @@ hipError_t LaunchBucketSort(hipStream_t stream, bool keyValue, bool atomicRank, 
 
 hipError_t LaunchHistogram(hipStream_t stream, uint32_t grid, const uint32_t* keys, uint32_t maxCount,
                            const uint32_t* countPtr, uint32_t* globalHistogram, uint32_t* tickets, void* statusClear,
-                           uint32_t statusClearBytes) {
+                           uint32_t statusClearBytes, uint32_t* top9Table) {
   u32x4* const clear = reinterpret_cast<u32x4*>(statusClear);
   const uint32_t vecs = statusClearBytes / 16u;  // whole status rows: a multiple of 1 KiB, 128-byte aligned
-  if (maxCount >= kHistManyCopiesFrom)
-    return Launch(reinterpret_cast<const void*>(&histogram_kernel<kHistCopiesLarge>), grid, kHistThreads,
-                  HistLdsBytes(kHistCopiesLarge), stream, keys, maxCount, countPtr, globalHistogram, tickets, clear, vecs);
-  return Launch(reinterpret_cast<const void*>(&histogram_kernel<kHistCopies>), grid, kHistThreads,
-                HistLdsBytes(kHistCopies), stream, keys, maxCount, countPtr, globalHistogram, tickets, clear, vecs);
+  const bool many = maxCount >= kHistManyCopiesFrom;
+  const void* kernel;
+  uint32_t lds;
+  if (top9Table != nullptr) {  // the nine-bit plan is recorded: the top nine bits instead of byte 3
+    kernel = many ? reinterpret_cast<const void*>(&histogram_kernel<kHistCopiesLarge, true>)
+                  : reinterpret_cast<const void*>(&histogram_kernel<kHistCopies, true>);
+    lds = HistTop9LdsBytes(many ? kHistCopiesLarge : kHistCopies);
+  } else {
+    kernel = many ? reinterpret_cast<const void*>(&histogram_kernel<kHistCopiesLarge, false>)
+                  : reinterpret_cast<const void*>(&histogram_kernel<kHistCopies, false>);
+    lds = HistLdsBytes(many ? kHistCopiesLarge : kHistCopies);
+  }
+  return Launch(kernel, grid, kHistThreads, lds, stream, keys, maxCount, countPtr, globalHistogram, tickets, clear, vecs,
+                top9Table);
+}
+
+hipError_t LaunchScatter9(hipStream_t stream, uint32_t grid, bool keyValue, const OnesweepArgs& args) {
+  const void* const kernel = keyValue ? reinterpret_cast<const void*>(&scatter9_kernel<true>)
+                                      : reinterpret_cast<const void*>(&scatter9_kernel<false>);
+  return Launch(kernel, grid, kScatter9Threads, kScatter9LdsWords * sizeof(uint32_t), stream, args);
+}
+
+hipError_t LaunchBucketSort9(hipStream_t stream, bool keyValue, const BucketSortArgs& args) {
+  const size_t lds = (keyValue ? SmallSortLdsWords<1024, 32, true>() : SmallSortLdsWords<1024, 32, false>()) * 4;
+  const void* const kernel = keyValue ? reinterpret_cast<const void*>(&bucket_sort_kernel<1024, 32, true, true, 512>)
+                                      : reinterpret_cast<const void*>(&bucket_sort_kernel<1024, 32, false, true, 512>);
+  return Launch(kernel, 512, 1024, lds, stream, args);
 }
 
 hipError_t LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool keyValue, bool atomicRank,

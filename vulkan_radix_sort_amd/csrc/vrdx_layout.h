@@ -94,6 +94,9 @@ struct StorageLayout {
   uint64_t ticketOffset;     // uint32[2], zeroed by the histogram kernel
   uint64_t failureOffset;    // uint32
   uint64_t histogramOffset;  // uint32[4][256]
+  uint64_t top9Offset;       // uint32[512]: counts of the keys' top nine bits (nine-bit hybrid plan only), behind the table
+  uint64_t status9Offset;    // uint32[tiles9 - 1][512]: status rows of scatter9_kernel (nine-bit hybrid plan only)
+  uint64_t status9Bytes;
   uint64_t statusOffset;     // uint32[2][rows + blockRows][256]: tile rows, then block rows, per region
   uint64_t statusRows;       // tile rows per region = max(tiles - 1, 0)
   uint64_t blockRows;        // block-sum rows per region (one per 32 tiles); 0 = classic look-back
@@ -109,8 +112,11 @@ struct StorageLayout {
 // tiles: status rows are sized for this many tiles (PlanTiles); storageAddress: the absolute address of the storage
 // (buffer + storageOffset) -- only its low 7 bits matter; the sizes do not depend on it.
 // blockSums: the sort uses block sums (PlanTiles said so): one more row per 32 tiles in each status region.
+// tiles9: tiles of scatter9_kernel when the nine-bit hybrid plan is recorded next to the passes (0: it is not): the 512
+// nine-bit counts follow the histogram table (one fill clears both) and that launch's status rows, 2 KiB each, sit in
+// front of status region 0 (the histogram kernel clears both in one sweep).
 static inline StorageLayout MakeLayout(uint32_t maxElementCount, uint32_t align, uint64_t tiles,
-                                       uint64_t storageAddress = 0, bool blockSums = false) {
+                                       uint64_t storageAddress = 0, bool blockSums = false, uint64_t tiles9 = 0) {
   StorageLayout l;
   const uint64_t elementCountSize = Align((uint32_t)sizeof(uint32_t), align);
   const uint64_t histogramSize = HistogramSize(maxElementCount, align);
@@ -118,15 +124,18 @@ static inline StorageLayout MakeLayout(uint32_t maxElementCount, uint32_t align,
   l.countOffset = VRDX_OFF_COUNT;
   l.failureOffset = VRDX_OFF_FAILURE;
   l.histogramOffset = elementCountSize;
-  const uint64_t tableEnd = l.histogramOffset + VRDX_PASSES * VRDX_RADIX * sizeof(uint32_t);
-  l.statusOffset = tableEnd + ((0 - (storageAddress + tableEnd)) & 127u);
+  l.top9Offset = l.histogramOffset + VRDX_PASSES * VRDX_RADIX * sizeof(uint32_t);
+  const uint64_t tableEnd = l.top9Offset + (tiles9 != 0 ? 512 * sizeof(uint32_t) : 0);
+  l.status9Offset = tableEnd + ((0 - (storageAddress + tableEnd)) & 127u);
+  l.status9Bytes = tiles9 > 1 ? (tiles9 - 1) * 512 * sizeof(uint32_t) : 0;
+  l.statusOffset = l.status9Offset + l.status9Bytes;
   l.statusRows = tiles > 0 ? tiles - 1 : 0;
   l.blockRows = blockSums ? (tiles + VRDX_BLOCK_TILES - 1) / VRDX_BLOCK_TILES : 0;
   l.regionBytes = (l.statusRows + l.blockRows) * VRDX_RADIX * sizeof(uint32_t);
   // count + plan word + failure word + global histogram: what the histogram kernel's atomics and the passes' first
   // reads need zeroed BEFORE that kernel starts; status region 0 is zeroed by the histogram kernel itself
   l.clearBytes = tableEnd;
-  l.statusClearBytes = l.regionBytes;
+  l.statusClearBytes = l.status9Bytes + l.regionBytes;  // from status9Offset
   l.ticketOffset = l.statusOffset + 2 * l.regionBytes;
   l.inoutOffset = l.ticketOffset + 128;
   l.valuesOffset = l.inoutOffset + (((uint64_t)maxElementCount * sizeof(uint32_t) + 127u) & ~(uint64_t)127u);
@@ -135,6 +144,21 @@ static inline StorageLayout MakeLayout(uint32_t maxElementCount, uint32_t align,
   l.keysOnlySize = refInoutOffset + inoutSize;
   l.keyValueSize = refInoutOffset + Align((uint32_t)inoutSize, align) + inoutSize;
   return l;
+}
+
+// Everything the layout places lies inside what the caller allocated (the key+value size is the larger one; a keys-only
+// sort never touches the values scratch).
+static inline bool LayoutFits(const StorageLayout& l, uint32_t maxElementCount) {
+  const uint64_t bytes = (uint64_t)maxElementCount * sizeof(uint32_t);
+  return l.inoutOffset + bytes <= l.keysOnlySize && l.valuesOffset + bytes <= l.keyValueSize;
+}
+
+// The nine-bit hybrid plan's scatter (scatter9_kernel) cuts the sort into equal tiles, two rounds of them on `cus` CUs:
+// slots of 64 keys per wave of its 1024 threads (a multiple of four, 8 ... 32).  Its status rows are 2 KiB per tile.
+static inline uint32_t Scatter9Slots(uint32_t elementCount, uint32_t cus) {
+  uint32_t slots = 4u * RoundUp(RoundUp(elementCount, 2u * cus), 4096u);
+  if (slots < 8u) slots = 8u;
+  return slots > 32u ? 32u : slots;
 }
 
 // Tile plan.  The 1024x32 kernels hold one workgroup per CU, so a sort of T full tiles takes ceil(T / CUs) rounds
