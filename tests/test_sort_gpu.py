@@ -540,8 +540,9 @@ def test_nine_bit_hybrid_plan_and_its_fallback_at_the_sub_bucket_capacity(torch_
     iota = np.arange(n, dtype=np.uint32)
     for heavy in (cap, cap + 1):
         k = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
-        top9 = k >> 23
-        k[top9 == 0x155] ^= np.uint32(1 << 23)                       # nobody has the nine-bit value 0x155 ...
+        mine = (k >> 23) == 0x155                                    # nobody has the nine-bit value 0x155 ...
+        elsewhere = rng.integers(0, 0x155, size=int(mine.sum()), dtype=np.uint64).astype(np.uint32)   # (spread over others)
+        k[mine] = (k[mine] & np.uint32(0x007FFFFF)) | (elsewhere << np.uint32(23))
         where = rng.choice(n, size=heavy, replace=False)
         k[where] = (k[where] & np.uint32(0x007FFFFF)) | np.uint32(0x155 << 23)   # ... except exactly `heavy` keys
         assert int(((k >> 23) == 0x155).sum()) == heavy

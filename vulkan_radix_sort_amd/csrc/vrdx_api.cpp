@@ -325,7 +325,10 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   static const int blockSumsKnob = TuningKnob("VRDX_BLOCK_SUMS");
   const bool blockSums = tilePlan.blockSums && hybridCap == 0 && blockSumsKnob != 0;
   uint8_t* const storage = BufferAddress(storageBuffer, storageOffset);
-  const uint32_t slots9 = vrdx::Scatter9Slots(elementCount, (uint32_t)sorter->computeUnits);
+  static const int slots9Knob = TuningKnob("VRDX_SCATTER9_SLOTS");  // measurements: 8 ... 32, a multiple of four
+  const uint32_t slots9 = slots9Knob >= 8 && slots9Knob <= 32 && slots9Knob % 4 == 0
+                              ? (uint32_t)slots9Knob
+                              : vrdx::Scatter9Slots(elementCount, (uint32_t)sorter->computeUnits);
   uint32_t tiles9 = cap9 != 0 ? vrdx::RoundUp(elementCount, slots9 * 1024u) : 0u;
   vrdx::StorageLayout layout = vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, tilePlan.tiles,
                                                 (uint64_t)reinterpret_cast<uintptr_t>(storage), blockSums, tiles9);

@@ -559,12 +559,11 @@ __device__ __forceinline__ void StoreQuad(uint32_t* out, uint32_t index, u32x4 q
 }
 
 // RADIX: digits per status row (256; 512 in the nine-bit scatter: two groups of 512 threads then).
-template <int THREADS, int RADIX = 256>
+template <int THREADS, int RADIX = 256, int W = kLookBackWindow>
 __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t tile, int tid, uint32_t* lds,
                                              uint32_t* failure, uint32_t* stickyFailure, uint32_t spinLimit,
                                              uint32_t* traceTripsRows) {
   constexpr int GROUPS = THREADS / RADIX;
-  constexpr int W = kLookBackWindow;
   int32_t* const pos = reinterpret_cast<int32_t*>(lds);
   uint32_t* const sum = lds + RADIX;
   uint32_t* const info = sum + GROUPS * RADIX;
@@ -1563,6 +1562,10 @@ constexpr uint32_t kScatter9Tile = kScatter9Threads * kScatter9Kpt;
 constexpr uint32_t kTop9 = 512;
 constexpr uint32_t kTop9Shift = 23;
 constexpr size_t kScatter9LdsWords = (size_t)kScatter9Tile + (size_t)(kScatter9Threads / 64) * kTop9;
+#ifndef VRDX_SCATTER9_WINDOW
+#define VRDX_SCATTER9_WINDOW 16
+#endif
+constexpr int kScatter9Window = VRDX_SCATTER9_WINDOW;  // rows per thread and look-back trip: two groups of 512 threads cover 2 x 16 tiles
 static_assert(kScatter9LdsWords * 4 <= 160 * 1024, "fits the CU's LDS");
 
 template <bool KV>
@@ -1587,8 +1590,11 @@ __global__ __launch_bounds__(kScatter9Threads) void scatter9_kernel(OnesweepArgs
   const int wave = tid >> 6;
 
   // the verdict, the same in every workgroup: does any nine-bit value occur more than cap9 times?
+  // (The ticket is drawn at once, together with the loads of the 512 counts -- one global round trip on the tile's
+  // critical path instead of two; it is this launch's own ticket word, so drawing one for nothing does no harm.)
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   const uint32_t bucketCount = tid < (int)kTop9 ? a.top9Table[tid] : 0u;
+  if (tid == 0) misc[0] = atomicAdd(a.ticketCur, 1u);
   const uint64_t over = __ballot(bucketCount > a.cap9);
   if (lane == 0) misc[1 + wave] = over != 0ull ? 1u : 0u;
   for (int i = tid; i < WAVES * (int)kTop9; i += THREADS) waveHist[i] = 0;
@@ -1597,9 +1603,6 @@ __global__ __launch_bounds__(kScatter9Threads) void scatter9_kernel(OnesweepArgs
 #pragma unroll
   for (int w = 0; w < WAVES; ++w) anyOver |= misc[1 + w];
   if (anyOver != 0 || n == 0) return;  // uniform: the plan does not apply, the four passes run
-  LdsBarrier();  // misc is read; the ticket goes into it next
-  if (tid == 0) misc[0] = atomicAdd(a.ticketCur, 1u);  // a ticket word of this launch's own (the passes have theirs)
-  LdsBarrier();
   const uint32_t tile = misc[0];
   if (tile == 0 && tid == 0) *a.planWord = 3u;  // for the launches behind this one: nothing left to do but the buckets
   const uint32_t slots = a.slots;               // per wave, a multiple of four, <= KPT
@@ -1648,7 +1651,8 @@ __global__ __launch_bounds__(kScatter9Threads) void scatter9_kernel(OnesweepArgs
   LdsBarrier();  // waveHist is dead from here on
 
   if (tile != 0)
-    exclusive = LookBack<THREADS, (int)kTop9>(a.statusCur, tile, tid, waveHist, a.failure, a.stickyFailure, a.spinLimit, nullptr);
+    exclusive = LookBack<THREADS, (int)kTop9, kScatter9Window>(a.statusCur, tile, tid, waveHist, a.failure, a.stickyFailure,
+                                                               a.spinLimit, nullptr);
   if (tid < (int)kTop9) {
     if (!lastTile)
       StoreStatus(&a.statusCur[tile * kTop9 + tid],
@@ -1660,43 +1664,58 @@ __global__ __launch_bounds__(kScatter9Threads) void scatter9_kernel(OnesweepArgs
   // the ranking and the regroup of 32 keys per lane) and land while the keys are scattered
   if constexpr (KV) LoadStriped<KPT, false, DYN>(a.valuesCaller, loadBase, tileEnd, valid == frame, 0u, val, slots);  // pad: downsweep.slang:85
 
-  // scatter: four consecutive staging words per lane; whole single-digit quads as one 16-byte store, the others word by
-  // word; four quads per batch (reads, then digits and offsets, then stores)
+  // scatter: four consecutive staging words per lane.  The main loop stores ONLY whole single-digit quads (one 16-byte
+  // store each, four quads per batch: reads, then digits and offsets, then stores); the quads that straddle a run boundary
+  // -- one in twelve with 48-key runs, but some lane of nearly every wave instruction has one, and a wave walks through
+  // every branch any of its lanes takes -- are stored afterwards, word by word, by the thread that knows where they are:
+  // thread d holds the tile-local start of digit d's run (ScatterStagedKeys of the pass kernels does the same).
   constexpr int QUADS = KPT / 4;
   constexpr int B = 4;
-  uint32_t quadDigits[KV ? QUADS : 1][2];  // key+value: the four digits of every quad, for the value phase
+  uint32_t quadDigits[KV ? QUADS : 1];  // key+value: first | last << 16 digit of every main-loop quad, for the value phase
+  uint32_t boundaryDigits[2] = {0, 0};  // the four digits of this thread's boundary quad
+  uint32_t boundaryQuad = ~0u;
+  if (tid < (int)kTop9 && count != 0 && (tileExclusive & 3u) != 0 && tileExclusive < valid) boundaryQuad = tileExclusive & ~3u;
+  if (tid == 0 && (valid & 3u) != 0) boundaryQuad = valid & ~3u;
   auto scatterQuads = [&](uint32_t* out, bool keysPhase) {
 #pragma unroll
     for (int j0 = 0; j0 < QUADS; j0 += B) {
       if (4u * (uint32_t)j0 * THREADS >= valid) break;  // batches of quads beyond the tile's keys are not read at all
       u32x4 w4[B];
+      uint32_t o[B];
+      bool whole[B];
 #pragma unroll
       for (int b = 0; b < B; ++b) w4[b] = *reinterpret_cast<const u32x4*>(&sorted[4u * (tid + (j0 + b) * THREADS)]);
 #pragma unroll
       for (int b = 0; b < B; ++b) {
         const int j = j0 + b;
         const uint32_t p = StagingSlot<TILE>(4u * (tid + j * THREADS));  // involution: the sorted position of the quad
-        uint32_t d[4];
+        uint32_t d0, d3;
         if (keysPhase) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) d[c] = (w4[b][c] >> kTop9Shift) & MASK;
-          if constexpr (KV) {
-            quadDigits[j][0] = d[0] | (d[1] << 16);
-            quadDigits[j][1] = d[2] | (d[3] << 16);
-          }
+          d0 = (w4[b][0] >> kTop9Shift) & MASK;
+          d3 = (w4[b][3] >> kTop9Shift) & MASK;
+          if constexpr (KV) quadDigits[j] = d0 | (d3 << 16);
         } else {
-          d[0] = quadDigits[KV ? j : 0][0] & 0xFFFFu;
-          d[1] = quadDigits[KV ? j : 0][0] >> 16;
-          d[2] = quadDigits[KV ? j : 0][1] & 0xFFFFu;
-          d[3] = quadDigits[KV ? j : 0][1] >> 16;
+          d0 = quadDigits[KV ? j : 0] & 0xFFFFu;
+          d3 = quadDigits[KV ? j : 0] >> 16;
         }
-        if (p + 3 < valid && d[0] == d[3]) {
-          StoreQuad(out, tileOffset[d[0]] + p, w4[b]);
-        } else {
+        whole[b] = p + 3 < valid && d0 == d3;
+        o[b] = tileOffset[d0] + p;
+        asm volatile("" : "+v"(o[b]));  // fetched here, for every quad: not sunk into the conditional store
+      }
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            if (p + c < valid) StoreWord(out, tileOffset[d[c]] + p + c, w4[b][c]);
-        }
+      for (int b = 0; b < B; ++b)
+        if (whole[b]) StoreQuad(out, o[b], w4[b]);
+    }
+    if (boundaryQuad != ~0u) {
+      const u32x4 q = *reinterpret_cast<const u32x4*>(&sorted[StagingSlot<TILE>(boundaryQuad)]);
+      if (keysPhase) {
+        boundaryDigits[0] = ((q[0] >> kTop9Shift) & MASK) | (((q[1] >> kTop9Shift) & MASK) << 16);
+        boundaryDigits[1] = ((q[2] >> kTop9Shift) & MASK) | (((q[3] >> kTop9Shift) & MASK) << 16);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t d = (boundaryDigits[c / 2] >> (16 * (c % 2))) & 0xFFFFu;
+        if (boundaryQuad + c < valid) StoreWord(out, tileOffset[d] + boundaryQuad + c, q[c]);
       }
     }
   };
