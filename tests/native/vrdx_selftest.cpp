@@ -354,7 +354,8 @@ int Parity(Harness& h, bool quick) {
     run(Mode::Keys, k, v, 300000, "storage reuse");
   }
   for (int kv = 0; kv < 2; ++kv)
-    for (uint32_t n : {5000u, 200000u, 3000000u}) {
+    for (uint32_t n : {5000u, 200000u, 3000000u, 12000000u}) {  // one launch | eight-bit hybrid plan | ... | nine-bit plan
+      if (quick && n > 3000000u) continue;
       ++cases;
       if (!GraphCase(h, kv != 0, n)) ++failures;
     }

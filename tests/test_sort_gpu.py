@@ -529,7 +529,8 @@ def test_tail_split_tiles_at_their_boundaries(torch_mod, sorter, oracle, n, key_
 
 @pytest.mark.parametrize("n", [ROUND + 12345, 12_000_001, 16_200_000])
 def test_nine_bit_hybrid_plan_and_its_fallback_at_the_sub_bucket_capacity(torch_mod, sorter, oracle, n):
-    """Sorts of 8.1 M < N <= 16.2 M elements record the nine-bit hybrid plan in front of their four passes: one stable
+    """Sorts of 8.4 M (one round of 32768-element tiles) < N <= 16.2 M elements record the nine-bit hybrid plan in front of
+    their four passes: one stable
     scatter by the top nine bits (scatter9_kernel), then 512 sub-buckets of at most 32768 elements each sorted inside one
     workgroup; the DEVICE keeps the four passes when a nine-bit value occurs more often than that.  Uniform keys with ONE
     nine-bit value brought to exactly 32768 occurrences (plan applies: word 1 of the storage says 3) and to 32769 (four

@@ -200,18 +200,20 @@ uint32_t HybridCapacity(bool atomicRank, uint32_t elementCount) {
 // The nine-bit hybrid plan (scatter9_kernel + 512 sub-bucket sorts, vrdx_kernels.hip) carries the two-trip plan past the
 // point where a bucket of the top byte no longer fits a workgroup: recorded -- in front of the passes, which return on its
 // verdict -- for sorts beyond the eight-bit plan's reach whose mean sub-bucket N / 512 leaves 3 % of room in 32768
-// (8.1 M < N <= 16.2 M elements; one-atomic ranking only, like the 32768-element buckets).  Returns the capacity or 0.
+// (one round of 32768-element tiles < N <= 16.2 M elements; one-atomic ranking only, like the 32768-element buckets).  Returns the capacity or 0.
 // Measured (profiles/r04_nine_bit_plan.txt): key+value 0.80-0.83 x the time of the four passes over the whole range
 // (58-76 instead of 48-62 GItems/s), keys-only 0.90-0.95 x (its scatter by nine bits is no match for a pass of the
 // two-sub-tile kernel -- 43 against 29 us at 12.6 M keys -- and the four returning passes cost 4.4 us each).
 // VRDX_HYBRID=0 and a forced tile geometry switch it off with the eight-bit plan, VRDX_HYBRID9=0 alone.
-uint32_t Hybrid9Capacity(bool atomicRank, uint32_t elementCount, uint32_t hybridCap) {
+uint32_t Hybrid9Capacity(bool atomicRank, uint32_t elementCount, uint32_t hybridCap, uint32_t cus) {
   static const bool enabled = [] {
     const char* all = std::getenv("VRDX_HYBRID");
     const char* nine = std::getenv("VRDX_HYBRID9");
     return (all == nullptr || all[0] != '0') && (nine == nullptr || nine[0] != '0');
   }();
-  if (!enabled || !atomicRank || hybridCap != 0 || elementCount <= 256u * 16384u) return 0;
+  // (not for sorts of exactly one round of 32768-element tiles or less: there the four passes are at their best -- one
+  // round, block sums -- and as fast (keys-only) or 5 % faster (key+value) than the nine-bit plan)
+  if (!enabled || !atomicRank || hybridCap != 0 || (uint64_t)elementCount <= (uint64_t)cus * 32768u) return 0;
   static const int knobLast = TuningKnob("VRDX_HYBRID_HEADROOM_LAST");
   const uint64_t mean = (elementCount + 511u) / 512u;
   const uint64_t need = mean * (uint64_t)(knobLast > 0 ? knobLast : 103) / 100u;
@@ -316,7 +318,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
 
   const bool atomicRank = sorter->atomicRank.load(std::memory_order_relaxed);  // one answer for the whole sort
   const uint32_t hybridCap = ForcedConfigIndex() < 0 ? HybridCapacity(atomicRank, elementCount) : 0u;
-  uint32_t cap9 = ForcedConfigIndex() < 0 ? Hybrid9Capacity(atomicRank, elementCount, hybridCap) : 0u;
+  uint32_t cap9 = ForcedConfigIndex() < 0 ? Hybrid9Capacity(atomicRank, elementCount, hybridCap, (uint32_t)sorter->computeUnits) : 0u;
   const int configIndex = ConfigIndex(sorter, keyValue, elementCount, atomicRank, cap9 != 0);
   const vrdx::TilePlan tilePlan = PlanTiles(sorter, configIndex, keyValue, elementCount, atomicRank);
   // Block sums instead of the look-back chain: sorts of one round (PlanTiles) on the four-pass plan -- with a hybrid
