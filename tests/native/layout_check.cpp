@@ -47,9 +47,10 @@ int main() {
             ok = ok && plan.tiles - plan.fullTiles <= cus;
           }
         }
-        // the nine-bit hybrid plan (recorded for 4.2 M < N <= 16.3 M next to passes of 32768-key tiles and more): its
-        // 512 counts and its status rows of 2 KiB per 16384 keys must fit as well, at every alignment
-        if (g.keysPerThread == 32 && cus == 256 && n > 256u * 16384u && ((uint64_t)(n + 511) / 512) * 103 / 100 <= 32768) {
+        // the nine-bit hybrid plan (Hybrid9Capacity in vrdx_api.cpp: recorded for sorts of more than one round of
+        // 32768-element tiles whose mean nine-bit sub-bucket leaves 3 % of room in 32768, next to passes of 32768-key tiles
+        // and more): its 512 counts and its status rows of 2 KiB per tile must fit as well, at every alignment
+        if (g.keysPerThread == 32 && (uint64_t)n > (uint64_t)cus * 32768u && ((uint64_t)(n + 511) / 512) * 103 / 100 <= 32768) {
           const uint64_t tiles9 = vrdx::RoundUp(n, vrdx::Scatter9Slots(n, cus) * 1024u);
           for (uint32_t address = 0; address < 128; address += 16) {
             const vrdx::StorageLayout l9 =
