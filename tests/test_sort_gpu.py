@@ -487,7 +487,7 @@ def test_four_pass_plan_at_mid_sizes_with_the_hybrid_plan_switched_off():
                                256 * 2048 * 32 - 4095])
 def test_even_split_tiles_at_their_slot_boundaries(torch_mod, sorter, oracle, n):
     """Keys-only sorts of one round of 1024x32 / 1024x32x2 tiles are cut into 256 EQUAL tiles of s slots per wave
-    (EvenSplitSlots in vrdx_api.cpp, s a multiple of 4): sizes that fill s slots exactly, that need one key more
+    (PlanTiles in vrdx_layout.h, s a multiple of 4): sizes that fill s slots exactly, that need one key more
     (s + 4), and ragged ones, direct and indirect with a smaller count (whole tiles past the count, a ragged tile in
     the middle of the grid)."""
     k, _ = oracle.generate(11, n, 32)

@@ -6,8 +6,8 @@
 //   * vrdxCmdSort* validate nothing, allocate nothing, never block the host: they append
 //     stream-ordered work to the hipStream_t passed as VkCommandBuffer, the way gpuSort()
 //     (:344-507) appends commands to a VkCommandBuffer.
-// What differs is the recorded work: 1 clear + 1 fused histogram + 4 onesweep launches instead of
-// 2 transfers + 12 dispatches + 12 barriers.
+// What differs is the recorded work: 1 clear + 1 fused histogram + 4 onesweep launches (+ the one or two launches of a
+// hybrid plan for mid-size sorts) instead of 2 transfers + 12 dispatches + 12 barriers.
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>

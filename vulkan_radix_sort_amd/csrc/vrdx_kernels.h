@@ -122,8 +122,8 @@ hipError_t LaunchSmallSort(hipStream_t stream, bool atomicRank, uint32_t* keys, 
                            const uint32_t* countPtr, uint32_t* failure);
 
 // Mid-size sorts, hybrid plan (PassPlan in vrdx_kernels.hip): launch 0 scatters by the keys' highest byte that varies,
-// bucket_sort_kernel sorts each of the 256 buckets by the bytes below it inside one workgroup.  hybridCap = 4096, 8192 or 16384
-// elements per bucket (1024 threads x 4 / 8 / 16); the device decides whether the plan applies.
+// bucket_sort_kernel sorts each of the 256 buckets by the bytes below it inside one workgroup.  hybridCap = 4096, 8192, 16384
+// or 32768 elements per bucket (1024 threads x 4 / 8 / 16 / 32); the device decides whether the plan applies.
 struct BucketSortArgs {
   const uint32_t* keysScratch;
   uint32_t* keysCaller;

@@ -18,8 +18,10 @@
 //     coherent), regroups keys by digit in LDS and writes them out four at a time with consecutive
 //     lanes on consecutive addresses; values replay the permutation through the same LDS buffer.
 //   * onesweep_pair_kernel -- the same pass with TWO 32768-key sub-tiles per workgroup, one ticket,
-//     one status row and one look-back for both (keys-only sorts of one to two and of four "rounds"
-//     of tiles per CU, see ConfigIndex in vrdx_api.cpp).
+//     one status row and one look-back for both (every keys-only sort beyond one "round" of tiles per CU,
+//     see ConfigIndex in vrdx_api.cpp).
+//   * small_sort_kernel / bucket_sort_kernel / scatter9_kernel -- sorts of up to 16384 elements in one workgroup;
+//     the two hybrid plans of mid-size sorts (one scatter by the top eight or nine bits, then every bucket in LDS).
 //   Tile ids are handed out by an atomic ticket in ARRIVAL order, so a look-back only ever waits
 //   on a tile that is already running; every spin is bounded (failure word, never a hang).
 #include <hip/hip_runtime.h>
@@ -1096,9 +1098,10 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   // Launches 1-3 of a sort whose hybrid plan applies have nothing to do, and launch 0 has said so in one word: they
   // return after one load instead of after the table, the ticket, the votes and a barrier (4 -> 2 us per empty launch).
   // (Not compiled into the key+value 1024x32 form with tiles of full capacity, the kernel of the 2^25 headline: the two
-  // lines cost it two registers and 1.7 % there, measured.  The hybrid plan ends at 7.6 M pairs, i.e. inside one round
-  // of tiles, where key+value sorts run the form with run-time slot counts (even-split tiles) of this geometry; a sort
-  // that does meet the full-capacity form with a hybrid plan recorded takes the long way to the same verdict.)
+  // lines cost it two registers and 1.7 % there, measured.  Key+value sorts of 4.4 ... 8.1 M pairs do meet that form
+  // with the hybrid plan recorded: their launches 1-3 take the long way to the same verdict, ~2 us each.  Running them on
+  // the form with run-time slot counts instead -- which has the word, but fetches its values late -- measured the same
+  // within 1 %, VRDX_EVEN_SPLIT=1, so they stay on this one.)
   constexpr bool kVerdictWord = !(KV && KPT == 32 && !DYN);
   if constexpr (kVerdictWord) {
     if (a.hybridCap != 0 && a.pass != 0 && *a.planWord == 1u) return;
