@@ -989,3 +989,45 @@ def test_sorter_status_is_sticky_across_sorts_sharing_one_storage(torch_mod, sor
     assert sorter.read_sorter_status(stream) == 0
     for (dk, dv), (ek, ev, _) in zip(buffers, expected):
         assert np.array_equal(_to_u32(dk), ek) and np.array_equal(_to_u32(dv), ev)
+
+
+def test_recheck_and_event_overhead_helpers(torch_mod, oracle):
+    """vrdxHipRecheck repeats the device check behind the one-atomic ranking (and leaves a healthy sorter as it was);
+    vrdxHipEventOverheadNs calibrates what a pair of event records adds to the kernel between them, against a kernel that
+    times itself with the device's wall clock: a few microseconds, never zero, never the 40 us the kernel itself runs."""
+    import vulkan_radix_sort_amd as vrdx
+    s = vrdx.Sorter()
+    s.recheck()
+    k, v = oracle.generate(3, 300_001, 32)
+    ek, ev, _ = oracle.sort(k, v)
+    gk, gv = gpu_sort(torch_mod, s, k, v)
+    assert np.array_equal(gk, ek) and np.array_equal(gv, ev)
+    stream = torch_mod.cuda.current_stream().cuda_stream
+    ns = vrdx.event_overhead_ns(stream)
+    assert 200 < ns < 20_000, ns
+    assert s.read_sorter_status(stream) == 0
+    s.destroy()
+
+
+def test_destroying_a_sorter_with_unread_failures_says_so():
+    """The entry points return void like the reference's: a caller that never asks vrdxHipReadSorterStatus still learns
+    that a sort gave up a look-back -- vrdxDestroySorter prints one line on stderr (test build: a spin limit of 0 and a
+    delayed tile 0 make tile 1 give up, deterministically), and nothing when the status was read or clean."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, numpy as np, torch\n"
+        "import vulkan_radix_sort_amd as vrdx\n"
+        "s = vrdx.Sorter(0); st = torch.cuda.current_stream().cuda_stream; n = 1 << 24\n"
+        "keys = torch.from_numpy(np.random.default_rng(1).integers(0, 2**32, n, dtype=np.uint32).view(np.int32)).cuda()\n"
+        "storage = torch.empty(s.storage_requirements(n).size, dtype=torch.uint8, device='cuda')\n"
+        "s.cmd_sort(st, n, keys.data_ptr(), 0, storage.data_ptr(), 0); torch.cuda.synchronize()\n"
+        "if sys.argv[1] == 'read': print('status 0x%x' % s.read_sorter_status(st))\n"
+        "s.destroy()\n")
+    env = dict(os.environ, VRDX_TEST_SPIN_LIMIT="0", VRDX_LIBRARY=os.path.join(ROOT, "build", "testing", "libvrdx_hip.so"))
+    unread = subprocess.run([sys.executable, "-c", code, "unread"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert unread.returncode == 0, unread.stderr[-2000:]
+    assert "sorter destroyed with unreported failures" in unread.stderr and "look-back spin expired" in unread.stderr
+    read = subprocess.run([sys.executable, "-c", code, "read"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert read.returncode == 0 and "status 0x1" in read.stdout, read.stdout + read.stderr[-2000:]
+    assert "sorter destroyed with unreported failures" not in read.stderr
