@@ -649,11 +649,12 @@ int Adversarial(Harness& h, int lg) {
 // against the oracle -- hunts rare cross-workgroup races (status hand-off, ticket, LDS ranking)
 // that a single pass over the parity battery could miss.  Two streams alternate so that sorts of
 // different sizes overlap on the device.
-int Soak(Harness& h, int seconds) {
+// maxN: largest element count drawn (3 M by default; 20 M reaches the nine-bit plan, the tail split and block sums, at a
+// few seconds of oracle time per sort).
+int Soak(Harness& h, int seconds, uint32_t maxN = 3u << 20) {
   std::mt19937 g(12345);
   hipStream_t second;
   HIP_OK(hipStreamCreate(&second));
-  const uint32_t maxN = 3u << 20;
   const uint32_t inoutMax = Align16(maxN * 4u);
   VrdxSorterStorageRequirements req;
   vrdxGetSorterKeyValueStorageRequirements(h.sorter, maxN, &req);
@@ -760,7 +761,8 @@ int main(int argc, char** argv) {
     BackToBack(h, argc > 2 ? std::atoi(argv[2]) : 25, argc > 3 && std::string(argv[3]) == "kv", argc > 4 ? std::atoi(argv[4]) : 10);
     return 0;
   }
-  if (what == "soak") return Soak(h, argc > 2 ? std::atoi(argv[2]) : 30) ? 1 : 0;
+  if (what == "soak")  // soak [seconds] [max elements]
+    return Soak(h, argc > 2 ? std::atoi(argv[2]) : 30, argc > 3 ? (uint32_t)std::strtoul(argv[3], nullptr, 10) : 3u << 20) ? 1 : 0;
   if (what == "adversarial") return Adversarial(h, argc > 2 ? std::atoi(argv[2]) : 25) ? 1 : 0;
   if (what == "bench") {
     std::vector<int> logs;
