@@ -199,6 +199,7 @@ uint32_t vrdxHipReadSorterStatus(VrdxSorter sorter, VkCommandBuffer commandBuffe
  * them never read -- the vrdxCmdSort* entry points return void like the reference's, so nothing fails silently): */
 #define VRDX_HIP_STATUS_LOOKBACK_GAVE_UP 0x00000001u /* a bounded look-back spin expired: that sort's result is unspecified */
 #define VRDX_HIP_STATUS_RANK_ORDER       0x00000002u /* the periodic repeat of the LDS lane-order check failed: vrdxHipRecheck */
+#define VRDX_HIP_STATUS_COUNT_CLAMPED    0x40000000u /* elementCount > 2^30 - 4 (where the reference's uint32 size math wraps, src/vk_radix_sort.h.in:105-115): the first 2^30 - 4 elements were sorted, the rest left alone */
 #define VRDX_HIP_STATUS_ENQUEUE_REFUSED  0x80000000u /* the HIP runtime refused a fill, copy or launch of a sort */
 
 /* Repeats, synchronously (~1 ms), the device check vrdxCreateSorter ran for the one-atomic ranking (LDS returning atomics
@@ -214,6 +215,26 @@ VkResult vrdxHipRecheck(VrdxSorter sorter);
  * differences of the 15-slot timestamp contract include this much on top of the kernel's duration; bench.py subtracts
  * it to report kernel time (synchronises the stream; ~0.5 ms).  ~0 on failure is not assumed: returns UINT64_MAX then. */
 uint64_t vrdxHipEventOverheadNs(VkCommandBuffer commandBuffer);
+
+/* Which plan vrdxCmdSort* records for a sort of `elementCount` elements with this sorter (it depends on the count, the
+ * device's CU count and the ranking mode only), and the HBM bytes per element that plan moves when the device lets it
+ * run -- what a roofline figure for the whole sort has to be priced with.  Plans other than FOUR_PASSES and
+ * ONE_WORKGROUP are taken or turned down ON THE DEVICE (a bucket that does not fit a workgroup's LDS: skewed keys), in
+ * which case the four passes recorded behind them run and `fallbackBytesPerElement` applies. */
+#define VRDX_HIP_PLAN_NONE 0u          /* elementCount == 0: nothing is recorded */
+#define VRDX_HIP_PLAN_ONE_WORKGROUP 1u /* <= 16384 elements: one launch, one load and one store of the data */
+#define VRDX_HIP_PLAN_FOUR_PASSES 2u   /* fused histogram + four onesweep passes: 36 B/key, 68 B/pair */
+#define VRDX_HIP_PLAN_HYBRID8 3u       /* histogram + one scatter by the highest varying byte + one in-LDS sort per bucket */
+#define VRDX_HIP_PLAN_HYBRID9 4u       /* the same with the top nine bits, 512 buckets */
+#define VRDX_HIP_PLAN_MSD 5u           /* histogram + scatter by the top 10 / 11 bits + two in-LDS passes per bucket */
+typedef struct VrdxHipPlanInfo {
+  uint32_t plan;                    /* VRDX_HIP_PLAN_* */
+  uint32_t bits;                    /* digits of the plan's scatter through memory (8, 9, 10, 11; 0 otherwise) */
+  uint32_t bytesPerElement;         /* algorithmic HBM bytes per element when the plan runs */
+  uint32_t fallbackBytesPerElement; /* ... when the device turns it down (== bytesPerElement for plans decided on the host) */
+  uint32_t launches;                /* kernel launches recorded (fills and copies not counted) */
+} VrdxHipPlanInfo;
+void vrdxHipDescribePlan(VrdxSorter sorter, uint32_t elementCount, int keyValue, VrdxHipPlanInfo* info);
 
 /* Library build info: "vrdx-hip <version> gfx950 tiles at 2^25: keys=<threads>x<keys per thread>[x<sub-tiles>]
  * key-value=... (size-adaptive | forced)". */

@@ -363,6 +363,45 @@ int Parity(Harness& h, bool quick) {
   return failures;
 }
 
+// The MSD plan (16.25 M elements and more): uniform keys at sizes on both sides of its ten- / eleven-bit ranges in every
+// mode, and inputs the DEVICE must turn it down for (a bucket beyond the capacity: the four passes recorded behind it run).
+// argv sizes override the list.
+int MsdParity(Harness& h, const std::vector<uint32_t>& wanted) {
+  int failures = 0, cases = 0;
+  auto run = [&](Mode m, const std::vector<uint32_t>& k, const std::vector<uint32_t>& v, uint32_t maxCount, const char* label) {
+    ++cases;
+    if (!RunCase(h, m, k, v, maxCount, label, true)) ++failures;
+    std::fflush(stdout);
+  };
+  std::vector<uint32_t> sizes = wanted;
+  if (sizes.empty()) sizes = {16252929u, 20000003u, 1u << 25, 36000001u, 45000000u};
+  for (uint32_t n : sizes) {
+    std::vector<uint32_t> v;
+    auto k = Mt(n, 1, 32, &v);
+    run(Mode::Keys, k, v, n, "msd uniform");
+    run(Mode::KeyValue, k, v, n, "msd uniform");
+    run(Mode::KeyValueIndirect, k, v, n + n / 7 + 5000, "msd uniform, larger bound");
+    run(Mode::KeysIndirect, k, v, n + 70000, "msd uniform, larger bound");
+    std::vector<uint32_t> iota(n);
+    for (uint32_t i = 0; i < n; ++i) iota[i] = i;
+    // 24-bit keys: every key in the top buckets 0..7 -- overflow, the four passes (one of them trivial) run
+    auto k24 = Mt(n, 3, 24, nullptr);
+    run(Mode::KeyValue, k24, iota, n, "msd declines: 24-bit keys");
+    // duplicates inside buckets that fit: stability of the scatter and of both bucket passes (keys = 11 top bits | 3 low bits)
+    std::mt19937 g(11);
+    std::vector<uint32_t> dup(n);
+    for (auto& x : dup) { const uint32_t r = g(); x = (r & 0xFFE00000u) | (r & 7u) | ((r >> 3 & 1u) << 12); }
+    run(Mode::KeyValue, dup, iota, n, "msd duplicates values=iota");
+    // one heavy bucket among uniform ones: a tenth of the keys share their top 11 bits
+    for (uint32_t i = 0; i < n; ++i) dup[i] = (g() % 10u == 0) ? (0x5A400000u | (g() & 0x1FFFFFu)) : g();
+    run(Mode::KeyValue, dup, iota, n, "msd declines: one heavy bucket");
+    for (uint32_t i = 0; i < n; ++i) dup[i] = n - 1 - i;
+    run(Mode::Keys, dup, iota, n, "msd declines: descending");
+  }
+  std::printf("msd parity: %d cases, %d failures\n", cases, failures);
+  return failures;
+}
+
 uint64_t Median(std::vector<uint64_t> v) {
   std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
   return v[v.size() / 2];
@@ -721,6 +760,11 @@ int main(int argc, char** argv) {
   h.init();
   std::printf("%s\n", vrdxHipVersionString());
   if (what == "parity" || what == "quick") return Parity(h, what == "quick") ? 1 : 0;
+  if (what == "msd") {  // msd [n ...]
+    std::vector<uint32_t> sizes;
+    for (int i = 2; i < argc; ++i) sizes.push_back((uint32_t)std::strtoul(argv[i], nullptr, 10));
+    return MsdParity(h, sizes) ? 1 : 0;
+  }
   if (what == "trace") {  // one sort, for tools/trace.sh (stamps are dumped by vrdxDestroySorter)
     const uint32_t n = 1u << (argc > 2 ? std::atoi(argv[2]) : 25);
     const bool kv = argc > 3 && std::string(argv[3]) == "kv";

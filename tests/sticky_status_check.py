@@ -10,6 +10,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["VRDX_TEST_SPIN_LIMIT"] = "0"
+# the CLASSIC look-back, the path with the spin: a sort of 2^24 keys would otherwise take the MSD plan (no look-back at all)
+# or, with that off, block sums (one round of tiles: nothing is published behind the test's delay of tile 0)
+os.environ["VRDX_MSD"] = "0"
+os.environ["VRDX_BLOCK_SUMS"] = "0"
 os.environ["VRDX_LIBRARY"] = os.path.join(ROOT, "build", "testing", "libvrdx_hip.so")
 sys.path.insert(0, ROOT)
 import numpy as np

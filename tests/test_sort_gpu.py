@@ -1024,7 +1024,9 @@ def test_destroying_a_sorter_with_unread_failures_says_so():
         "s.cmd_sort(st, n, keys.data_ptr(), 0, storage.data_ptr(), 0); torch.cuda.synchronize()\n"
         "if sys.argv[1] == 'read': print('status 0x%x' % s.read_sorter_status(st))\n"
         "s.destroy()\n")
-    env = dict(os.environ, VRDX_TEST_SPIN_LIMIT="0", VRDX_LIBRARY=os.path.join(ROOT, "build", "testing", "libvrdx_hip.so"))
+    # (VRDX_MSD=0, VRDX_BLOCK_SUMS=0: the classic look-back is the path with the spin; see tests/sticky_status_check.py)
+    env = dict(os.environ, VRDX_TEST_SPIN_LIMIT="0", VRDX_MSD="0", VRDX_BLOCK_SUMS="0",
+               VRDX_LIBRARY=os.path.join(ROOT, "build", "testing", "libvrdx_hip.so"))
     unread = subprocess.run([sys.executable, "-c", code, "unread"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert unread.returncode == 0, unread.stderr[-2000:]
     assert "sorter destroyed with unreported failures" in unread.stderr and "look-back spin expired" in unread.stderr

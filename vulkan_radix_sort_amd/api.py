@@ -52,13 +52,18 @@ EXPORTED_SYMBOLS = (
     "vrdxHipReadSorterStatus",
     "vrdxHipRecheck",
     "vrdxHipEventOverheadNs",
+    "vrdxHipDescribePlan",
     "vrdxHipVersionString",
 )
 
 # bits of vrdxHipReadSorterStatus (include/vk_radix_sort.h)
 STATUS_LOOKBACK_GAVE_UP = 0x00000001
 STATUS_RANK_ORDER = 0x00000002
+STATUS_COUNT_CLAMPED = 0x40000000
 STATUS_ENQUEUE_REFUSED = 0x80000000
+
+# VRDX_HIP_PLAN_* (include/vk_radix_sort.h)
+PLAN_NAMES = {0: "none", 1: "one-workgroup", 2: "four-passes", 3: "hybrid-8", 4: "hybrid-9", 5: "msd"}
 
 
 class VrdxError(RuntimeError):
@@ -78,6 +83,16 @@ class VrdxSorterCreateInfo(ctypes.Structure):
 class VrdxSorterStorageRequirements(ctypes.Structure):
     # src/vk_radix_sort.h.in:28-31
     _fields_ = [("size", ctypes.c_uint64), ("usage", ctypes.c_uint32)]
+
+
+class VrdxHipPlanInfo(ctypes.Structure):
+    # include/vk_radix_sort.h
+    _fields_ = [("plan", ctypes.c_uint32), ("bits", ctypes.c_uint32), ("bytesPerElement", ctypes.c_uint32),
+                ("fallbackBytesPerElement", ctypes.c_uint32), ("launches", ctypes.c_uint32)]
+
+    @property
+    def name(self) -> str:
+        return PLAN_NAMES.get(int(self.plan), "?")
 
 
 def in_tree_library_path() -> str:
@@ -155,6 +170,8 @@ def load_library() -> ctypes.CDLL:
     lib.vrdxHipRecheck.argtypes = [vp]
     lib.vrdxHipEventOverheadNs.restype = u64
     lib.vrdxHipEventOverheadNs.argtypes = [vp]
+    lib.vrdxHipDescribePlan.restype = None
+    lib.vrdxHipDescribePlan.argtypes = [vp, u32, ctypes.c_int, ctypes.POINTER(VrdxHipPlanInfo)]
     lib.vrdxHipVersionString.restype = ctypes.c_char_p
     lib.vrdxHipVersionString.argtypes = []
     _LIB = lib
@@ -293,6 +310,13 @@ class Sorter:
         whatever storage they used (``vrdxHipReadSorterStatus``); synchronises the stream."""
         return int(self._lib.vrdxHipReadSorterStatus(self.handle, _handle(command_buffer)))
 
+
+    def describe_plan(self, element_count: int, key_value: bool) -> VrdxHipPlanInfo:
+        """``vrdxHipDescribePlan``: the plan this sorter records for that many elements and the HBM bytes per element it
+        moves (what a whole-sort roofline figure is priced with)."""
+        info = VrdxHipPlanInfo()
+        self._lib.vrdxHipDescribePlan(self.handle, element_count, 1 if key_value else 0, ctypes.byref(info))
+        return info
 
     def recheck(self) -> None:
         """``vrdxHipRecheck``: repeats the device check behind the one-atomic ranking and falls back to the ballot

@@ -133,7 +133,8 @@ class HipShardExecutor:
 def describe_status(word: int) -> str:
     """The independent diagnoses of vrdxHipReadSorterStatus (include/vk_radix_sort.h, VRDX_HIP_STATUS_*): bit 0 = a
     look-back gave up on the DEVICE (bounded spin expired, the result of that sort is unspecified); bit 1 = the periodic
-    repeat of the LDS lane-order check failed (the one-atomic ranking rests on it: call ``Sorter.recheck``); bit 31 = the
+    repeat of the LDS lane-order check failed (the one-atomic ranking rests on it: call ``Sorter.recheck``); bit 30 = an element count beyond
+    2^30 - 4 (where the reference's uint32 size math wraps) was clamped; bit 31 = the
     RUNTIME refused an enqueue of a sort (fill, copy or kernel launch) on the host side, i.e. that sort never ran as
     recorded."""
     if word == 0:
@@ -147,8 +148,10 @@ def describe_status(word: int) -> str:
         parts.append("a device-side look-back spin expired (bit 0)")
     if word & 0x2:
         parts.append("LDS atomics were seen out of lane order by the periodic re-check (bit 1)")
-    if word & 0x7FFFFFFC:
-        parts.append("unknown bits 0x%x" % (word & 0x7FFFFFFC))
+    if word & 0x40000000:
+        parts.append("an element count beyond 2^30 - 4 was clamped: that sort's tail is unsorted (bit 30)")
+    if word & 0x3FFFFFFC:
+        parts.append("unknown bits 0x%x" % (word & 0x3FFFFFFC))
     return "; ".join(parts)
 
 

@@ -41,6 +41,8 @@ struct VrdxSorter_T {
   // refused by the runtime -- the entry points return void, so this is the only place it can go.
   // Reported as bit 31 by vrdxHipReadSorterStatus, which clears it.
   mutable std::atomic<uint32_t> enqueueFailed{0};
+  // A sort was recorded with more than VRDX_MAX_ELEMENTS elements and clamped (bit 30 of vrdxHipReadSorterStatus).
+  mutable std::atomic<uint32_t> countClamped{0};
   // reference: VrdxSorter_T::minStorageBufferOffsetAlignment (src/vk_radix_sort.h.in:134)
   uint32_t minStorageBufferOffsetAlignment = VRDX_STORAGE_ALIGN;
 };
@@ -220,6 +222,41 @@ uint32_t Hybrid9Capacity(bool atomicRank, uint32_t elementCount, uint32_t hybrid
   return need <= 32768u ? 32768u : 0u;
 }
 
+// The MSD plan (vrdx_kernels.hip, "MSD plan"): one stable scatter by the keys' top 10 or 11 bits, then every bucket by its
+// remaining bits in two passes inside one workgroup -- three ranking steps and two trips through memory instead of four
+// and four.  Recorded, in front of the four passes (which return on its verdict), for sorts beyond the eight- and nine-bit
+// plans' reach whose mean bucket leaves 3 % of room in the bucket kernel's capacity (uniform keys spread by half a percent
+// at these sizes): ten bits up to 36.6 M keys / 32.5 M pairs, eleven bits up to twice that.  Returns the bits or 0.
+// One-atomic ranking only.  VRDX_MSD=0 switches it off (VRDX_HYBRID=0 and a forced tile geometry as well); VRDX_MSD_FROM=n
+// records it from n elements up instead (measurements: below its default range it replaces the other two plans).
+uint32_t MsdTileKeys(uint32_t elementCount) {
+  static const int knob = TuningKnob("VRDX_MSD_TILE");  // measurements: 16384 | 32768
+  const uint32_t wanted = knob == 16384 ? 16384u : vrdx::kMsdTileKeys;
+  return vrdx::RoundUp(elementCount, wanted) <= vrdx::kMsdMaxTiles ? wanted : vrdx::kMsdTileKeys;
+}
+
+uint32_t MsdBits(bool atomicRank, bool keyValue, uint32_t elementCount, uint32_t* capacity) {
+  static const bool enabled = [] {
+    const char* all = std::getenv("VRDX_HYBRID");
+    const char* msd = std::getenv("VRDX_MSD");
+    return (all == nullptr || all[0] != '0') && (msd == nullptr || msd[0] != '0');
+  }();
+  static const int from = TuningKnob("VRDX_MSD_FROM");
+  static const int forcedBits = TuningKnob("VRDX_MSD_BITS");  // measurements: 10 | 11 wherever the capacity allows
+  static const int knobLast = TuningKnob("VRDX_HYBRID_HEADROOM_LAST");
+  if (!enabled || !atomicRank) return 0;
+  const uint32_t lowest = from > 0 ? (uint32_t)from : 16252929u;  // where the nine-bit plan ends
+  if (elementCount < lowest || vrdx::RoundUp(elementCount, vrdx::kMsdTileKeys) > vrdx::kMsdMaxTiles) return 0;
+  const uint32_t cap = keyValue ? vrdx::kMsdCapKeyValue : vrdx::kMsdCapKeys;
+  *capacity = cap;
+  for (uint32_t bits = 10; bits <= 11; ++bits) {
+    if (forcedBits > 0 && (uint32_t)forcedBits != bits) continue;
+    const uint64_t mean = ((uint64_t)elementCount + (1u << bits) - 1u) >> bits;
+    if (mean * (uint64_t)(knobLast > 0 ? knobLast : 103) / 100u <= cap) return bits;
+  }
+  return 0;
+}
+
 bool SmallSortEnabled() {
   static const bool enabled = [] {
     const char* env = std::getenv("VRDX_SMALL_SORT");  // "0": always take the general path (testing)
@@ -300,7 +337,13 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   hipStream_t stream = reinterpret_cast<hipStream_t>(commandBuffer);
   VrdxHipQueryPool* pool = reinterpret_cast<VrdxHipQueryPool*>(queryPool);
   const bool keyValue = valuesBuffer != nullptr;
-  if (elementCount > VRDX_MAX_ELEMENTS) elementCount = VRDX_MAX_ELEMENTS;
+  if (elementCount > VRDX_MAX_ELEMENTS) {
+    // The reference's uint32 byte math wraps above 2^30 - 4 elements (src/vk_radix_sort.h.in:105-115): no storage
+    // requirement exists for such a count.  The first 2^30 - 4 elements are sorted, the tail is left alone, and the
+    // sorter's status word says so (VRDX_HIP_STATUS_COUNT_CLAMPED) -- like every other failure mode, never silently.
+    elementCount = VRDX_MAX_ELEMENTS;
+    sorter->countClamped.store(1u, std::memory_order_relaxed);
+  }
 
   // Launches go to the sorter's device (a Vulkan command buffer belongs to one device too); the
   // calling thread's current device is put back afterwards.
@@ -317,30 +360,55 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   } deviceScope(sorter->device);
 
   const bool atomicRank = sorter->atomicRank.load(std::memory_order_relaxed);  // one answer for the whole sort
-  const uint32_t hybridCap = ForcedConfigIndex() < 0 ? HybridCapacity(atomicRank, elementCount) : 0u;
-  uint32_t cap9 = ForcedConfigIndex() < 0 ? Hybrid9Capacity(atomicRank, elementCount, hybridCap, (uint32_t)sorter->computeUnits) : 0u;
-  const int configIndex = ConfigIndex(sorter, keyValue, elementCount, atomicRank, cap9 != 0);
-  const vrdx::TilePlan tilePlan = PlanTiles(sorter, configIndex, keyValue, elementCount, atomicRank);
+  uint32_t msdCap = 0;
+  uint32_t msdBits = ForcedConfigIndex() < 0 ? MsdBits(atomicRank, keyValue, elementCount, &msdCap) : 0u;
+  const uint32_t hybridCap = ForcedConfigIndex() < 0 && msdBits == 0 ? HybridCapacity(atomicRank, elementCount) : 0u;
+  uint32_t cap9 = ForcedConfigIndex() < 0 && msdBits == 0
+                      ? Hybrid9Capacity(atomicRank, elementCount, hybridCap, (uint32_t)sorter->computeUnits)
+                      : 0u;
+  const int configIndex = ConfigIndex(sorter, keyValue, elementCount, atomicRank, cap9 != 0 || msdBits != 0);
+  vrdx::TilePlan tilePlan = PlanTiles(sorter, configIndex, keyValue, elementCount, atomicRank);
   // Block sums instead of the look-back chain: sorts of one round (PlanTiles) on the four-pass plan -- with a hybrid
   // plan recorded, launch 0 may rank by another byte than its pass index, which the block-sum form does not look up.
   // VRDX_BLOCK_SUMS=0 keeps the classic look-back (measurements).
   static const int blockSumsKnob = TuningKnob("VRDX_BLOCK_SUMS");
-  const bool blockSums = tilePlan.blockSums && hybridCap == 0 && blockSumsKnob != 0;
+  bool blockSums = tilePlan.blockSums && hybridCap == 0 && blockSumsKnob != 0;
   uint8_t* const storage = BufferAddress(storageBuffer, storageOffset);
   static const int slots9Knob = TuningKnob("VRDX_SCATTER9_SLOTS");  // measurements: 8 ... 32, a multiple of four
   const uint32_t slots9 = slots9Knob >= 8 && slots9Knob <= 32 && slots9Knob % 4 == 0
                               ? (uint32_t)slots9Knob
                               : vrdx::Scatter9Slots(elementCount, (uint32_t)sorter->computeUnits);
   uint32_t tiles9 = cap9 != 0 ? vrdx::RoundUp(elementCount, slots9 * 1024u) : 0u;
+  const uint32_t msdTileKeys = MsdTileKeys(elementCount);
+  const uint32_t msdTiles = vrdx::RoundUp(elementCount, msdTileKeys);
   vrdx::StorageLayout layout = vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, tilePlan.tiles,
-                                                (uint64_t)reinterpret_cast<uintptr_t>(storage), blockSums, tiles9);
-  if (cap9 != 0 && !vrdx::LayoutFits(layout, elementCount)) {
-    // (cannot happen for the sizes Hybrid9Capacity admits -- tests/native/layout_check.cpp sweeps them -- but the
-    // storage is the caller's: without the nine-bit plan's 2 KiB rows the layout fits for every N)
+                                                (uint64_t)reinterpret_cast<uintptr_t>(storage), blockSums, tiles9, msdBits,
+                                                msdTiles);
+  if ((cap9 != 0 || msdBits != 0) && !vrdx::LayoutFits(layout, elementCount)) {
+    // (cannot happen for the sizes Hybrid9Capacity / MsdBits admit -- tests/native/layout_check.cpp sweeps them -- but the
+    // storage is the caller's: without the plans' rows in front of the status regions the layout fits for every N)
     cap9 = 0;
     tiles9 = 0;
+    msdBits = 0;
     layout = vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, tilePlan.tiles,
                               (uint64_t)reinterpret_cast<uintptr_t>(storage), blockSums, 0);
+  }
+  if (!vrdx::LayoutFits(layout, elementCount)) {
+    // EVERY sort is checked, not only those with a plan in front: the layout depends on the tile plan, and the
+    // measurement knobs (VRDX_TAIL_SPLIT, VRDX_EVEN_SPLIT, VRDX_TILE_CONFIG) can select plans the offline sweep of
+    // tests/native/layout_check.cpp never saw.  Tiles of the kernel's full capacity without block rows fit for every N
+    // (2 (tiles - 1) KiB <= (P - 1) KiB from 8192 keys per tile up); smaller tiles cannot be helped: the scratch arrays
+    // must not leave the caller's allocation, so that sort is refused and says so (VRDX_HIP_STATUS_ENQUEUE_REFUSED).
+    tilePlan = vrdx::PlanTiles(elementCount, (uint32_t)sorter->computeUnits, (uint32_t)vrdx::kTileConfigs[configIndex].threads,
+                               (uint32_t)vrdx::kTileConfigs[configIndex].keysPerThread,
+                               (uint32_t)vrdx::kTileConfigs[configIndex].subTiles, false, false, 0);
+    blockSums = false;
+    layout = vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, tilePlan.tiles,
+                              (uint64_t)reinterpret_cast<uintptr_t>(storage), false, 0);
+    if (!vrdx::LayoutFits(layout, elementCount)) {
+      EnqueueCheck(sorter, "storage layout (status rows do not fit the reference's partition-histogram area)", hipErrorInvalidValue);
+      return;
+    }
   }
   uint32_t* const keys = reinterpret_cast<uint32_t*>(BufferAddress(keysBuffer, keysOffset));
   uint32_t* const values =
@@ -406,9 +474,19 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     if (grid == 0) grid = 1;
     static const int forcedGrid = TuningKnob("VRDX_HIST_GRID");  // tools/hist_grid.sh
     if (forcedGrid > 0) grid = (uint32_t)forcedGrid;
-    EnqueueCheck(sorter, "histogram_kernel",
-                 vrdx::LaunchHistogram(stream, grid, keys, elementCount, countPtr, globalHistogram, tickets,
-                                       storage + layout.status9Offset, (uint32_t)layout.statusClearBytes, top9Table));
+    if (msdBits != 0) {
+      // the MSD plan's form: top-bits counts per tile of 32768 keys (a workgroup takes whole tiles)
+      if (forcedGrid <= 0) grid = std::min<uint32_t>(msdTiles, cap);
+      EnqueueCheck(sorter, "histogram_msd_kernel",
+                   vrdx::LaunchHistogramMsd(stream, grid, keys, elementCount, countPtr, globalHistogram, tickets,
+                                            storage + layout.statusClearOffset, (uint32_t)layout.statusClearBytes,
+                                            reinterpret_cast<uint32_t*>(storage + layout.msdCountsOffset), msdTiles, msdBits,
+                                            msdTileKeys));
+    } else {
+      EnqueueCheck(sorter, "histogram_kernel",
+                   vrdx::LaunchHistogram(stream, grid, keys, elementCount, countPtr, globalHistogram, tickets,
+                                         storage + layout.statusClearOffset, (uint32_t)layout.statusClearBytes, top9Table));
+    }
   }
 
   const uint32_t tiles = tilePlan.tiles;
@@ -456,10 +534,49 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     b.top9Table = top9Table;
     EnqueueCheck(sorter, "bucket_sort_kernel (nine-bit)", vrdx::LaunchBucketSort9(stream, keyValue, b));
   }
+  // The MSD plan, recorded in front of the passes like the nine-bit plan: spine (prefixes over the tiles, bucket table,
+  // verdict), scatter by the top bits, one workgroup per bucket.  The passes behind return on the verdict word.
+  if (msdBits != 0) {
+    vrdx::MsdArgs m;
+    std::memset(&m, 0, sizeof(m));
+    m.keysCaller = keys;
+    m.keysScratch = keysScratch;
+    m.valuesCaller = keyValue ? values : nullptr;
+    m.valuesScratch = keyValue ? valuesScratch : nullptr;
+    m.maxCount = elementCount;
+    m.countPtr = countPtr;
+    m.histogramTable = globalHistogram;
+    m.tileCounts = reinterpret_cast<uint32_t*>(storage + layout.msdCountsOffset);
+    m.bucketBase = reinterpret_cast<uint32_t*>(storage + layout.msdBucketOffset);
+    m.bucketCount = m.bucketBase + ((size_t)1 << msdBits);
+    m.overflowWord = reinterpret_cast<uint32_t*>(storage + VRDX_OFF_MSD_OVERFLOW);
+    m.planWord = reinterpret_cast<uint32_t*>(storage + VRDX_OFF_PLAN);
+    m.bits = msdBits;
+    m.cap = msdCap;
+    m.tiles = msdTiles;
+    m.tileKeys = msdTileKeys;
+    // Timestamps: the plan's own three stages take the names they have in the reference -- slot 2 "upsweep" = the
+    // histogram, 3 "spine", 4 "downsweep" = the scatter -- and the bucket sorts are pass 1's "upsweep" (slot 5, like the
+    // eight-bit plan's); the four returning passes share the slots behind.
+    Stamp(pool, query + 2, stream);
+    EnqueueCheck(sorter, "spine_msd_kernel", vrdx::LaunchSpineMsd(stream, m));
+    Stamp(pool, query + 3, stream);
+    EnqueueCheck(sorter, "scatter_msd_kernel", vrdx::LaunchScatterMsd(stream, keyValue, m));
+    Stamp(pool, query + 4, stream);
+    EnqueueCheck(sorter, "bucket_sort2_kernel", vrdx::LaunchBucketSort2(stream, keyValue, m));
+    Stamp(pool, query + 5, stream);
+  }
   for (uint32_t pass = 0; pass < VRDX_PASSES; ++pass) {
     // "upsweep" of this pass: the fused histogram kernel for pass 0, nothing for the others -- the same
     // point of the stream as the previous pass's "downsweep" stamp
-    if (pass == 0) {
+    if (msdBits != 0) {
+      // (slots 2-5 are the MSD plan's, above; launch 0 and launch 1 fall into slot 7)
+      if (pass == 1) StampSame(pool, query + 6, query + 5);
+      if (pass >= 2) {
+        StampSame(pool, query + 2 + 3 * pass + 0, query + 2 + 3 * (pass - 1) + 2);
+        StampSame(pool, query + 2 + 3 * pass + 1, query + 2 + 3 * pass + 0);
+      }
+    } else if (pass == 0) {
       Stamp(pool, query + 2, stream);
     } else if (pass == 1 && hybridCap != 0) {
       // the hybrid plan's second half, between launch 0 and launch 1 (which is empty when the plan applies): its time
@@ -480,7 +597,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     } else {
       StampSame(pool, query + 2 + 3 * pass + 0, query + 2 + 3 * (pass - 1) + 2);
     }
-    StampSame(pool, query + 2 + 3 * pass + 1, query + 2 + 3 * pass + 0);  // "spine" (fused into the look-back)
+    if (msdBits == 0) StampSame(pool, query + 2 + 3 * pass + 1, query + 2 + 3 * pass + 0);  // "spine" (fused into the look-back)
 
     vrdx::OnesweepArgs args;
     // which pair of arrays the pass reads is settled on the device (vrdx_kernels.h); the reference
@@ -517,7 +634,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     if (testSpinLimit >= 0) args.spinLimit = (uint32_t)testSpinLimit;
 #endif
     args.earlyValues = earlyValues ? 1u : 0u;
-    args.cap9 = cap9;
+    args.cap9 = cap9 != 0 ? cap9 : msdCap * (msdBits != 0 ? 1u : 0u);  // non-zero: a plan in front may have taken the sort (verdict 3)
     args.top9Table = top9Table;
     args.slots = tilePlan.slots;
     args.fullTiles = tilePlan.fullTiles;
@@ -529,13 +646,19 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     EnqueueCheck(sorter, "onesweep_kernel",
                  vrdx::LaunchOnesweep(stream, configIndex, tiles, keyValue, atomicRank, args));
 
-    Stamp(pool, query + 2 + 3 * pass + 2, stream);  // "downsweep"
+    if (msdBits == 0 || pass != 0) Stamp(pool, query + 2 + 3 * pass + 2, stream);  // "downsweep"
   }
   StampSame(pool, query + 14, query + 13);  // end of the sort = end of the last pass
 
   // Behind every 65536th sort: 8 workgroups repeat the lane-order check of vrdxCreateSorter (~20 us, never blocks; a
   // mismatch sets VRDX_HIP_STATUS_RANK_ORDER in the sorter's status word, which vrdxHipReadSorterStatus and
   // vrdxDestroySorter report).
+  // Not into a stream capture: the check would be baked into the graph and run with every replay.  The count is not
+  // advanced then, so the first sort recorded outside a capture makes up for it.
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  if (atomicRank && (sorter->sortsRecorded.load(std::memory_order_relaxed) & 0xFFFFu) == 0xFFFFu &&
+      (hipStreamIsCapturing(stream, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone))
+    return;
   if (atomicRank && (sorter->sortsRecorded.fetch_add(1u, std::memory_order_relaxed) & 0xFFFFu) == 0xFFFFu)
     EnqueueCheck(sorter, "lds_order_check_kernel", vrdx::LaunchLdsOrderRecheck(stream, sorter->stickyStatus));
 }
@@ -573,6 +696,7 @@ VkResult vrdxCreateSorter(const VrdxSorterCreateInfo* pCreateInfo, VrdxSorter* p
   for (int i = 0; i < vrdx::kNumTileConfigs && e == hipSuccess; ++i) e = vrdx::PrepareKernels(i);
   if (e == hipSuccess) e = vrdx::PrepareSmallSort();
   if (e == hipSuccess) e = vrdx::PrepareBucketSort();
+  if (e == hipSuccess) e = vrdx::PrepareMsd();
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sorter->stickyStatus), sizeof(uint32_t));
   if (e == hipSuccess) e = hipMemset(sorter->stickyStatus, 0, sizeof(uint32_t));
   if (e == hipSuccess) {
@@ -614,14 +738,27 @@ void vrdxDestroySorter(VrdxSorter sorter) {
   // asks vrdxHipReadSorterStatus would not learn that a sort gave up a look-back (result unspecified), that the
   // lane-order re-check failed or that the runtime refused an enqueue.  One line on stderr, only if something did.
   if (sorter->stickyStatus != nullptr) {
+    // on the sorter's device, whatever the calling thread's current one is (one thread may own a sorter per GPU)
+    int previous = -1;
+    const bool switched = hipGetDevice(&previous) == hipSuccess && previous != sorter->device &&
+                          hipSetDevice(sorter->device) == hipSuccess;
+    struct Restore {
+      bool on;
+      int device;
+      ~Restore() {
+        if (on) (void)hipSetDevice(device);
+      }
+    } restore{switched, previous};
     uint32_t word = 0;
     if (hipMemcpy(&word, sorter->stickyStatus, sizeof(word), hipMemcpyDeviceToHost) != hipSuccess) word = 0;  // (synchronises)
     if (sorter->enqueueFailed.load(std::memory_order_relaxed) != 0) word |= VRDX_HIP_STATUS_ENQUEUE_REFUSED;
+    if (sorter->countClamped.load(std::memory_order_relaxed) != 0) word |= VRDX_HIP_STATUS_COUNT_CLAMPED;
     if (word != 0)
       std::fprintf(stderr,
-                   "vrdx-hip: sorter destroyed with unreported failures (status 0x%08x:%s%s%s) -- see vrdxHipReadSorterStatus\n",
+                   "vrdx-hip: sorter destroyed with unreported failures (status 0x%08x:%s%s%s%s) -- see vrdxHipReadSorterStatus\n",
                    word, (word & VRDX_HIP_STATUS_LOOKBACK_GAVE_UP) ? " a look-back spin expired, that sort's result is unspecified;" : "",
                    (word & VRDX_HIP_STATUS_RANK_ORDER) ? " LDS atomics were seen out of lane order, call vrdxHipRecheck;" : "",
+                   (word & VRDX_HIP_STATUS_COUNT_CLAMPED) ? " an element count beyond 2^30 - 4 was clamped, that sort's tail is unsorted;" : "",
                    (word & VRDX_HIP_STATUS_ENQUEUE_REFUSED) ? " the HIP runtime refused an enqueue;" : "");
     (void)hipFree(sorter->stickyStatus);
   }
@@ -757,6 +894,7 @@ uint32_t vrdxHipReadSorterStatus(VrdxSorter sorter, VkCommandBuffer commandBuffe
   // the copy above targets `word` on this stack frame: never return while it may still be in flight
   if (hipStreamSynchronize(stream) != hipSuccess || cleared != hipSuccess) return 0xFFFFFFFFu;
   if (sorter->enqueueFailed.exchange(0u, std::memory_order_relaxed) != 0) word |= VRDX_HIP_STATUS_ENQUEUE_REFUSED;
+  if (sorter->countClamped.exchange(0u, std::memory_order_relaxed) != 0) word |= VRDX_HIP_STATUS_COUNT_CLAMPED;
   return word;
 }
 
@@ -786,9 +924,20 @@ uint64_t vrdxHipEventOverheadNs(VkCommandBuffer commandBuffer) {
   unsigned long long* stamps = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   uint64_t result = ~0ull;
-  if (hipGetDevice(&device) != hipSuccess ||
+  // the stream's device, not the calling thread's current one (the null stream: the current device)
+  if ((stream != nullptr ? hipStreamGetDevice(stream, &device) : hipGetDevice(&device)) != hipSuccess ||
       hipDeviceGetAttribute(&clockKhz, hipDeviceAttributeWallClockRate, device) != hipSuccess || clockKhz <= 0)
     return result;
+  int previousDevice = -1;
+  const bool switchedDevice = hipGetDevice(&previousDevice) == hipSuccess && previousDevice != device &&
+                              hipSetDevice(device) == hipSuccess;
+  struct RestoreDevice {
+    bool on;
+    int device;
+    ~RestoreDevice() {
+      if (on) (void)hipSetDevice(device);
+    }
+  } restoreDevice{switchedDevice, previousDevice};
   if (hipMalloc(reinterpret_cast<void**>(&stamps), 2 * sizeof(unsigned long long)) != hipSuccess) return result;
   if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
     // a kernel that demonstrably runs 40 us, right behind another one (a busy stream, like the passes of a sort)
@@ -817,19 +966,69 @@ uint64_t vrdxHipEventOverheadNs(VkCommandBuffer commandBuffer) {
   return result;
 }
 
+void vrdxHipDescribePlan(VrdxSorter sorter, uint32_t elementCount, int keyValue, VrdxHipPlanInfo* info) {
+  if (info == nullptr) return;
+  std::memset(info, 0, sizeof(*info));
+  if (sorter == nullptr || elementCount == 0) return;
+  if (elementCount > VRDX_MAX_ELEMENTS) elementCount = VRDX_MAX_ELEMENTS;
+  const bool kv = keyValue != 0;
+  const uint32_t fourPasses = kv ? 68u : 36u;  // 4 (histogram) + 4 x (read + write)
+  const uint32_t twoTrips = kv ? 36u : 20u;    // 4 (histogram) + scatter (read + write) + buckets (read + write)
+  const bool atomicRank = sorter->atomicRank.load(std::memory_order_relaxed);
+  const bool adaptive = ForcedConfigIndex() < 0;
+  info->fallbackBytesPerElement = fourPasses;
+  if (elementCount <= vrdx::kSmallSortMaxElements && adaptive && SmallSortEnabled()) {
+    info->plan = VRDX_HIP_PLAN_ONE_WORKGROUP;
+    info->bytesPerElement = info->fallbackBytesPerElement = kv ? 16u : 8u;
+    info->launches = 1;
+    return;
+  }
+  uint32_t msdCap = 0;
+  const uint32_t msdBits = adaptive ? MsdBits(atomicRank, kv, elementCount, &msdCap) : 0u;
+  const uint32_t hybridCap = adaptive && msdBits == 0 ? HybridCapacity(atomicRank, elementCount) : 0u;
+  const uint32_t cap9 =
+      adaptive && msdBits == 0 ? Hybrid9Capacity(atomicRank, elementCount, hybridCap, (uint32_t)sorter->computeUnits) : 0u;
+  if (msdBits != 0) {
+    info->plan = VRDX_HIP_PLAN_MSD;
+    info->bits = msdBits;
+    info->bytesPerElement = twoTrips;
+    info->launches = 8;  // histogram, spine, scatter, buckets, four returning passes
+  } else if (cap9 != 0) {
+    info->plan = VRDX_HIP_PLAN_HYBRID9;
+    info->bits = 9;
+    info->bytesPerElement = twoTrips;
+    info->launches = 7;
+  } else if (hybridCap != 0) {
+    info->plan = VRDX_HIP_PLAN_HYBRID8;
+    info->bits = 8;
+    info->bytesPerElement = twoTrips;
+    info->launches = 6;
+  } else {
+    info->plan = VRDX_HIP_PLAN_FOUR_PASSES;
+    info->bytesPerElement = fourPasses;
+    info->launches = 5;
+  }
+}
+
 const char* vrdxHipVersionString(void) {
-  static char text[160];
-  VrdxSorter_T nominal;  // an MI355X: 256 CUs, lane-ordered LDS atomics
-  nominal.computeUnits = 256;
-  const vrdx::TileConfig& k = vrdx::kTileConfigs[ConfigIndex(&nominal, false, 1u << 25, true, false)];
-  const vrdx::TileConfig& kv = vrdx::kTileConfigs[ConfigIndex(&nominal, true, 1u << 25, true, false)];
-  char kName[32], kvName[32];
-  ConfigName(k, kName, sizeof(kName));
-  ConfigName(kv, kvName, sizeof(kvName));
-  std::snprintf(text, sizeof(text), "vrdx-hip %d.%d.%d gfx950 tiles at 2^25: keys=%s key-value=%s%s",
-                VRDX_VERSION_MAJOR, VRDX_VERSION_MINOR, VRDX_VERSION_PATCH, kName, kvName,
-                ForcedConfigIndex() >= 0 ? " (forced)" : " (size-adaptive)");
-  return text;
+  // built once (thread-safe static initialisation), never rewritten: concurrent callers read one immutable buffer
+  struct Text {
+    char text[160];
+    Text() {
+      VrdxSorter_T nominal;  // an MI355X: 256 CUs, lane-ordered LDS atomics
+      nominal.computeUnits = 256;
+      const vrdx::TileConfig& k = vrdx::kTileConfigs[ConfigIndex(&nominal, false, 1u << 25, true, false)];
+      const vrdx::TileConfig& kv = vrdx::kTileConfigs[ConfigIndex(&nominal, true, 1u << 25, true, false)];
+      char kName[32], kvName[32];
+      ConfigName(k, kName, sizeof(kName));
+      ConfigName(kv, kvName, sizeof(kvName));
+      std::snprintf(text, sizeof(text), "vrdx-hip %d.%d.%d gfx950 tiles at 2^25: keys=%s key-value=%s%s",
+                    VRDX_VERSION_MAJOR, VRDX_VERSION_MINOR, VRDX_VERSION_PATCH, kName, kvName,
+                    ForcedConfigIndex() >= 0 ? " (forced)" : " (size-adaptive)");
+    }
+  };
+  static const Text once;
+  return once.text;
 }
 
 }  // extern "C"

@@ -140,6 +140,49 @@ hipError_t PrepareBucketSort();
 hipError_t LaunchBucketSort(hipStream_t stream, bool keyValue, bool atomicRank, const BucketSortArgs& args);
 hipError_t LaunchBucketSort9(hipStream_t stream, bool keyValue, const BucketSortArgs& args);  // one-atomic ranking only
 
+// The MSD plan of large sorts (round 5; vrdx_kernels.hip, "MSD plan"): THREE ranking steps of 10-11 bits instead of four
+// of 8, and TWO trips of the data through memory instead of four --
+//   histogram_msd_kernel  the byte histograms (for the fallback) and, per tile of kMsdTileKeys keys, the counts of the
+//                         keys' top `bits` bits as 16-bit numbers (tileCounts);
+//   spine_msd_kernel      turns them, in place, into exclusive prefixes over the tiles and leaves every bucket's base and
+//                         size (bucketBase / bucketCount); a bucket beyond `cap` elements sets *overflowWord;
+//   scatter_msd_kernel    one stable scatter by those bits, caller -> scratch: no ticket, no look-back, no status words --
+//                         a tile's bases are bucketBase[d] + its row of prefixes;
+//   bucket_sort2_kernel   one workgroup per bucket sorts it by the remaining 21-22 bits in TWO stable passes of up to
+//                         11 bits inside its LDS, scratch -> caller.
+// All of it with wave-private counters of 16 bits, two to a word.  The device decides (the overflow word): with a bucket
+// beyond the capacity the last two return at once and the four passes recorded behind them run.
+constexpr uint32_t kMsdTileKeys = 32768;   // 1024 threads x 32 keys (16384 = x 16: two workgroups per CU)
+constexpr uint32_t kMsdMaxTiles = 2048;    // spine_msd_kernel: 64 chunks of at most 32 rows
+constexpr uint32_t kMsdCapKeys = 36864;    // bucket capacity, keys-only: 1024 threads x 36 keys (144 KiB of staging)
+constexpr uint32_t kMsdCapKeyValue = 36864;  // the same for pairs: keys and values take turns in the staging buffer
+struct MsdArgs {
+  uint32_t* keysCaller;
+  uint32_t* keysScratch;
+  uint32_t* valuesCaller;      // KV only
+  uint32_t* valuesScratch;     // KV only
+  uint32_t maxCount;           // element count (direct) or upper bound (indirect)
+  const uint32_t* countPtr;    // device-side element count (indirect) or nullptr
+  const uint32_t* histogramTable;  // uint[4][256]; the spine reads row 3
+  uint32_t* tileCounts;        // [tiles][2^bits / 2] words = pairs of 16-bit numbers: counts, then prefixes over the tiles
+  uint32_t* bucketBase;        // [2^bits]
+  uint32_t* bucketCount;       // [2^bits]
+  uint32_t* overflowWord;      // VRDX_OFF_MSD_OVERFLOW in the storage: non-zero = some bucket exceeds cap
+  uint32_t* planWord;          // VRDX_OFF_PLAN: the scatter writes 3 when the plan applies (the passes then return)
+  uint32_t bits;               // 10 | 11
+  uint32_t cap;                // elements a bucket may hold
+  uint32_t tiles;              // ceil(maxCount / tileKeys)
+  uint32_t tileKeys;           // 32768 | 16384
+};
+hipError_t PrepareMsd();
+hipError_t LaunchHistogramMsd(hipStream_t stream, uint32_t grid, const uint32_t* keys, uint32_t maxCount,
+                              const uint32_t* countPtr, uint32_t* globalHistogram, uint32_t* tickets, void* statusClear,
+                              uint32_t statusClearBytes, uint32_t* tileCounts, uint32_t tiles, uint32_t bits,
+                              uint32_t tileKeys);
+hipError_t LaunchSpineMsd(hipStream_t stream, const MsdArgs& args);
+hipError_t LaunchScatterMsd(hipStream_t stream, bool keyValue, const MsdArgs& args);
+hipError_t LaunchBucketSort2(hipStream_t stream, bool keyValue, const MsdArgs& args);
+
 // Runs the device self-check of the LDS same-address atomic ordering on the current device
 // (synchronous, ~1 ms).  *laneOrdered = true when returning atomics are served in lane order.
 hipError_t LdsOrderCheck(bool* laneOrdered);

@@ -1985,6 +1985,628 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(BucketSortArgs a) 
 }
 
 // ---------------------------------------------------------------------------------------------
+// MSD plan (round 5): three ranking steps of 10-11 bits, two trips through memory
+// ---------------------------------------------------------------------------------------------
+// A four-pass LSD sort moves every key through HBM four times, and each of the four passes costs a CU the same LDS work
+// per key (rank, regroup, read back) wherever the pass runs.  What LIMITS the digit width is the wave-private counter
+// table: 16 waves x 2^bits counters.  With counters of 16 bits, two to a 32-bit word -- a wave holds at most 2304 keys
+// and a workgroup at most 36864, so neither a count nor a position ever carries out of its half -- 2048 digits take the
+// 64 KiB that 1024 took, and 32 bits are three steps (10-11 | 11 | 10-11) instead of four.  The first step is a stable
+// scatter by the TOP bits through memory; the other two happen inside one workgroup per bucket:
+//
+//   histogram_msd_kernel   reads the keys once: byte histograms 0..2 like histogram_kernel, and the counts of the top
+//                          BITS bits PER TILE of 32768 keys, written out as 16-bit numbers (byte 3's histogram is
+//                          their sum) -- the reference's upsweep (upsweep.slang:10-45) for this one digit;
+//   spine_msd_kernel       exclusive prefix over the tiles, in place; base and size of every bucket; a bucket beyond
+//                          the capacity raises the overflow word (spine.slang:11-84);
+//   scatter_msd_kernel     stable scatter by the top bits: base = bucketBase[d] + prefix[tile][d] + rank in the tile
+//                          (downsweep.slang:41-224).  No ticket, no status words, no look-back, no spin: tiles are
+//                          independent, which is what a row of 2048 status words per tile would have made expensive;
+//   bucket_sort2_kernel    every bucket (<= 36864 keys / 32768 pairs) by its remaining 21-22 bits: two stable passes of
+//                          <= 11 bits through the LDS staging buffer.
+//
+// A stable scatter by the top bits followed by a stable sort of each bucket by the bits below is the permutation of
+// four stable LSD passes.  If any bucket exceeds the capacity (skewed or few-distinct keys, keys below 2^21) the last two
+// launches return and the four passes recorded behind them run as if nothing had happened.
+
+// Exclusive scan of one value per thread over all THREADS threads; one barrier inside; scratch: THREADS / 64 words that
+// nothing else touches until the next barrier.
+template <int THREADS>
+__device__ __forceinline__ uint32_t BlockExclusiveScanAll(uint32_t v, uint32_t* scratch, int tid) {
+  constexpr int WAVES = THREADS / 64;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const uint32_t x = WaveInclusiveScan(v);
+  if (lane == 63) scratch[wave] = x;
+  LdsBarrier();
+  uint32_t add = 0;
+#pragma unroll
+  for (int w = 0; w < WAVES - 1; ++w)
+    if (w < wave) add += scratch[w];
+  return x - v + add;
+}
+
+// A loop that is unrolled by construction: body(integral_constant<int, I>) for I = FIRST, FIRST + STEP, ... < LAST, until
+// it returns false.  (#pragma unroll gave up on the nine chunks of a 36-key lane -- multiple exits -- and a loop that is
+// not unrolled indexes its register arrays through scratch memory.)
+template <int FIRST, int LAST, int STEP, typename F>
+__device__ __forceinline__ void StaticFor(F&& body) {
+  if constexpr (FIRST < LAST) {
+    if (!body(std::integral_constant<int, FIRST>{})) return;
+    StaticFor<FIRST + STEP, LAST, STEP>(body);
+  }
+}
+
+// Stable rank of a key slot inside its wave with PACKED counters: digit d counts in bits [16 (d & 1), +16) of word
+// d >> 1 of the wave's row.  One returning LDS atomic per key, like RankAtomic: lanes of one instruction on one WORD are
+// served in ascending lane order whatever they add (lds_order_check_packed_kernel verifies exactly this shape), and a
+// wave's <= 2304 keys cannot carry out of a half.  Uniform slots (sorted or constant input) are ranked by one lane adding
+// 64; the test runs only in chunks whose first slot looks the part (see RankAtomic).  Ranks come two to a register.
+template <int KPT, bool DYN>
+__device__ __forceinline__ void RankPacked16(const uint32_t (&key)[KPT], uint32_t shift, uint32_t mask, uint32_t* myRow,
+                                             int lane, uint32_t (&out)[KPT / 2], uint32_t slots = KPT) {
+  constexpr int CHUNK = (!DYN && KPT % 8 == 0) ? 8 : 4;
+  static_assert(KPT % CHUNK == 0 && CHUNK % 2 == 0, "whole chunks of pairs");
+  StaticFor<0, KPT, CHUNK>([&](auto chunk) {
+    constexpr int base = decltype(chunk)::value;
+    if (DYN && (uint32_t)base >= slots) return false;
+    uint32_t r[CHUNK];
+    const uint32_t probe = (key[base] >> shift) & mask;
+    const bool watch = __popcll(__ballot(probe != (uint32_t)__builtin_amdgcn_readfirstlane(probe))) <= 48;  // wave-uniform
+    if (watch) {
+#pragma unroll
+      for (int c = 0; c < CHUNK; ++c) {
+        const uint32_t d = (key[base + c] >> shift) & mask;
+        const uint32_t sh = (d & 1u) * 16u;
+        const bool uniform = __ballot(d != (uint32_t)__builtin_amdgcn_readfirstlane(d)) == 0ull;  // wave-uniform
+        uint32_t old = 0;
+        if (!uniform || lane == 0)
+          old = __hip_atomic_fetch_add(&myRow[d >> 1], (uniform ? 64u : 1u) << sh, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (uniform) old = (uint32_t)__builtin_amdgcn_readfirstlane(old);
+        r[c] = ((old >> sh) & 0xFFFFu) + (uniform ? (uint32_t)lane : 0u);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CHUNK; ++c) {
+        const uint32_t d = (key[base + c] >> shift) & mask;
+        const uint32_t sh = (d & 1u) * 16u;
+        const uint32_t old =
+            __hip_atomic_fetch_add(&myRow[d >> 1], 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        r[c] = (old >> sh) & 0xFFFFu;
+      }
+    }
+#pragma unroll
+    for (int c = 1; c < CHUNK; c += 2) {
+      out[(base + c) / 2] = r[c - 1] | (r[c] << 16);
+      asm volatile("" : "+v"(out[(base + c) / 2]));  // pack now, not when first used
+    }
+    return true;
+  });
+}
+
+// The scan over the packed counters [WAVES][ROW]: thread `col` owns word `col` (two digits) of every wave's row.
+// ColumnTotals: both digits' counts over all waves (lo | hi << 16; <= 36864 each, no carry).  ColumnBases: replaces every
+// wave's count by `add` + the counts of the waves before it -- the position of the wave's first key of that digit.
+template <uint32_t ROW, int WAVES>
+__device__ __forceinline__ uint32_t ColumnTotals(const uint32_t* counters, uint32_t col) {
+  uint32_t total = 0;
+#pragma unroll
+  for (int w = 0; w < WAVES; ++w) total += counters[w * ROW + col];
+  return total;
+}
+template <uint32_t ROW, int WAVES>
+__device__ __forceinline__ void ColumnBases(uint32_t* counters, uint32_t col, uint32_t add) {
+  static_assert(WAVES % 8 == 0, "halves of eight: eight reads in flight, then eight stores");
+  uint32_t running = add;
+#pragma unroll
+  for (int w0 = 0; w0 < WAVES; w0 += 8) {
+    uint32_t c[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) c[w] = counters[(w0 + w) * ROW + col];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      counters[(w0 + w) * ROW + col] = running;
+      running += c[w];
+    }
+  }
+}
+
+// ranks -> physical staging slots, in place: slot = StagingSlot(row[digit] + rank).  Reads only; the staging buffer may
+// alias the counters once every wave has been through here (the caller's barrier).
+template <int KPT, uint32_t STAGE, bool DYN>
+__device__ __forceinline__ void PositionsPacked16(const uint32_t (&key)[KPT], uint32_t shift, uint32_t mask,
+                                                  const uint32_t* myRow, uint32_t (&rankThenSlot)[KPT / 2],
+                                                  uint32_t slots = KPT) {
+  constexpr int CHUNK = (!DYN && KPT % 8 == 0) ? 8 : 4;
+  StaticFor<0, KPT, CHUNK>([&](auto chunk) {
+    constexpr int base = decltype(chunk)::value;
+    if (DYN && (uint32_t)base >= slots) return false;
+    uint32_t w[CHUNK];
+#pragma unroll
+    for (int c = 0; c < CHUNK; ++c) w[c] = myRow[((key[base + c] >> shift) & mask) >> 1];
+#pragma unroll
+    for (int c = 0; c < CHUNK; ++c) {
+      const int i = base + c;
+      const uint32_t d = (key[i] >> shift) & mask;
+      const uint32_t r = (rankThenSlot[i / 2] >> (16 * (i % 2))) & 0xFFFFu;
+      w[c] = StagingSlot<STAGE>(((w[c] >> ((d & 1u) * 16u)) & 0xFFFFu) + r);
+    }
+#pragma unroll
+    for (int c = 1; c < CHUNK; c += 2) {
+      rankThenSlot[(base + c) / 2] = w[c - 1] | (w[c] << 16);
+      asm volatile("" : "+v"(rankThenSlot[(base + c) / 2]));
+    }
+    return true;
+  });
+}
+
+// ---- histogram_msd_kernel ---------------------------------------------------------------------------
+// histogram_kernel (same pipeline: two groups of four 16-byte loads per lane in flight, all workgroups inside one window of
+// the input) with the fourth table replaced: instead of byte 3 it counts the keys' top BITS bits, PER TILE of 32768 keys
+// (= two groups), in 2^BITS bins x TC replicas of 32 KiB in all, and after each tile writes the 2^BITS counts out as
+// 16-bit numbers (a tile holds 32768 keys: 0x8000 fits), adds them up into byte 3's histogram (4 or 8 bins each) and
+// clears them.  A wave whose 64 keys share their top bits (sorted, constant, narrow inputs: exactly the inputs this plan
+// will turn down) would serialise 16-way on TC replicas: one lane adds 64 instead.
+constexpr uint32_t kMsdTopBinWords = 8192;  // 32 KiB: 1024 bins x 8 replicas | 2048 x 4
+
+constexpr uint32_t HistMsdLdsBytes(uint32_t copies) { return (3u * 256u * copies + kMsdTopBinWords + 256u) * 4u; }
+
+template <uint32_t COPIES, uint32_t BITS, uint32_t GROUPS>
+__global__ __launch_bounds__(kHistThreads) void histogram_msd_kernel(const uint32_t* __restrict__ keys, uint32_t maxCount,
+                                                                      const uint32_t* countPtr,
+                                                                      uint32_t* __restrict__ globalHistogram,
+                                                                      uint32_t* __restrict__ tickets,
+                                                                      u32x4* __restrict__ statusClear, uint32_t statusVecs,
+                                                                      uint32_t* __restrict__ tileCounts, uint32_t tiles) {
+  static_assert(kHistThreads == 1024 && (GROUPS == 1 || GROUPS == 2), "a tile is one or two groups of 16384 keys");
+  constexpr uint32_t kTileVecLog = GROUPS == 2 ? 13u : 12u;  // 16-byte vectors per tile
+  constexpr uint32_t D = 1u << BITS;
+  constexpr uint32_t TC = kMsdTopBinWords / D;        // replicas of a top-bits bin
+  constexpr uint32_t kByteWords = 3u * VRDX_RADIX * COPIES;
+  constexpr uint32_t PER_BYTE = D / 512u;             // words (pairs of bins) per value of byte 3: 2 | 4
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  uint32_t* const bins = smem;                        // [3][256][COPIES]
+  uint32_t* const top = smem + kByteWords;            // [D][TC]
+  uint32_t* const byte3 = top + kMsdTopBinWords;      // [256], each word owned by one thread
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  if (blockIdx.x == 0 && tid < 3) tickets[tid] = 0;
+  const uint32_t n = ElementCount(maxCount, countPtr);
+
+  const uint32_t copy = tid & (COPIES - 1);
+  auto count = [&](uint32_t key) {
+#pragma unroll
+    for (uint32_t p = 0; p < 3; ++p) {
+      const uint32_t d = (key >> (8 * p)) & 0xFFu;
+      atomicAdd(&bins[(p * VRDX_RADIX + d) * COPIES + copy], 1u);
+    }
+    const uint32_t t = key >> (32u - BITS);
+    const uint64_t active = __ballot(true);  // (taken HERE: inside the one-lane branch below it would be that one lane)
+    const bool uniform = __ballot(t != (uint32_t)__builtin_amdgcn_readfirstlane(t)) == 0ull;  // among the active lanes
+    if (!uniform)
+      atomicAdd(&top[t * TC + (tid & (TC - 1))], 1u);
+    else if (lane == (uint32_t)__builtin_ctzll(active))
+      atomicAdd(&top[t * TC], (uint32_t)__popcll(active));
+  };
+  auto tally = [&](uint32_t group, const u32x4 (&k)[4], uint32_t nvec) {
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      if (group * kHistGroupVecs + u * kHistThreads + tid < nvec) {
+        count(k[u][0]);
+        count(k[u][1]);
+        count(k[u][2]);
+        count(k[u][3]);
+      }
+    }
+  };
+  // the tile's counts out, byte 3's share added up, the bins cleared
+  auto flush = [&](uint32_t tile) {
+    LdsBarrier();
+    for (uint32_t w = tid; w < D / 2; w += kHistThreads) {  // whole waves: D / 2 is a multiple of 64
+      uint32_t lo = 0, hi = 0;
+      u32x4* const mine = reinterpret_cast<u32x4*>(top + (size_t)w * 2u * TC);
+#pragma unroll
+      for (uint32_t q = 0; q < TC / 4; ++q) {
+        const u32x4 x = mine[q], y = mine[TC / 4 + q];
+        lo += x[0] + x[1] + x[2] + x[3];
+        hi += y[0] + y[1] + y[2] + y[3];
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < TC / 2; ++q) mine[q] = u32x4{0u, 0u, 0u, 0u};
+      tileCounts[(size_t)tile * (D / 2) + w] = lo | (hi << 16);
+      uint32_t s = lo + hi;
+      s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0xB1, 0xf, 0xf, true);  // quad_perm:[1,0,3,2]
+      if (PER_BYTE == 4) s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x4E, 0xf, 0xf, true);  // quad_perm:[2,3,0,1]
+      if ((w & (PER_BYTE - 1)) == 0) byte3[w / PER_BYTE] += s;
+    }
+    LdsBarrier();
+  };
+
+  const uint32_t nvec = n >> 2;
+  const u32x4* keys4 = reinterpret_cast<const u32x4*>(keys);
+  auto sweep = [&](auto streaming) {
+    constexpr bool NT = decltype(streaming)::value;
+    const uint32_t step = gridDim.x;
+    u32x4 a[4], b[4];
+    uint32_t tile = blockIdx.x;
+    const auto tail = [&](uint32_t t) {  // the last one to three keys belong to the tile that holds key n - 1
+      if (t == (nvec >> kTileVecLog) && tid < (n & 3u)) count(keys[(nvec << 2) + tid]);
+    };
+    if constexpr (GROUPS == 2) {
+      HistFetch<NT>(keys4, 2 * tile, tid, nvec, a);
+      HistFetch<NT>(keys4, 2 * tile + 1, tid, nvec, b);
+    } else {
+      HistFetch<NT>(keys4, tile, tid, nvec, a);
+      HistFetch<NT>(keys4, tile + step, tid, nvec, b);
+    }
+    for (uint32_t i = tid; i < kByteWords + kMsdTopBinWords + 256u; i += kHistThreads) bins[i] = 0;
+    LdsBarrier();
+    if constexpr (GROUPS == 2) {
+      for (; tile < tiles; tile += step) {
+        tally(2 * tile, a, nvec);
+        HistFetch<NT>(keys4, 2 * (tile + step), tid, nvec, a);
+        tally(2 * tile + 1, b, nvec);
+        HistFetch<NT>(keys4, 2 * (tile + step) + 1, tid, nvec, b);
+        tail(tile);
+        flush(tile);
+      }
+    } else {
+      for (; tile < tiles; tile += 2 * step) {
+        tally(tile, a, nvec);
+        HistFetch<NT>(keys4, tile + 2 * step, tid, nvec, a);
+        tail(tile);
+        flush(tile);
+        if (tile + step >= tiles) break;
+        tally(tile + step, b, nvec);
+        HistFetch<NT>(keys4, tile + 3 * step, tid, nvec, b);
+        tail(tile + step);
+        flush(tile + step);
+      }
+    }
+  };
+  const bool streamingInput = VRDX_HIST_NT == 2 || (VRDX_HIST_NT == 1 && n > kHistStreamingLoadsAbove);
+  if (streamingInput) {
+    asm volatile("; non-temporal key loads" ::: "memory");
+    sweep(std::true_type{});
+  } else {
+    sweep(std::false_type{});
+  }
+  for (uint32_t i = blockIdx.x * kHistThreads + tid; i < statusVecs; i += gridDim.x * kHistThreads)
+    statusClear[i] = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+
+  if (tid < 3 * VRDX_RADIX) {
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < COPIES; ++c) sum += bins[tid * COPIES + ((c + tid) & (COPIES - 1))];
+    if (sum != 0) atomicAdd(&globalHistogram[tid], sum);
+  } else {
+    const uint32_t sum = byte3[tid - 3 * VRDX_RADIX];
+    if (sum != 0) atomicAdd(&globalHistogram[tid], sum);
+  }
+}
+
+// ---- spine_msd_kernel -------------------------------------------------------------------------------
+// tileCounts[tile][w] (two 16-bit counts per word) -> exclusive prefixes over the tiles, in place; bucketBase / bucketCount.
+// One workgroup per 16 words (32 buckets): thread (chunk, word) adds up its chunk of the rows -- 64 chunks, at most 32 rows
+// each, every load in flight at once, 64 bytes per row and workgroup -- the 64 chunk sums of a word are scanned by one
+// wave, and the thread walks its rows again from registers.  Totals are kept in 32 bits per digit: a bucket beyond 65535
+// must not go unnoticed because its half wrapped (the prefixes it leaves are garbage then, and nobody reads them).
+// The first bucket's base is the number of keys below it: a prefix of byte 3's histogram.
+template <uint32_t BITS>
+__global__ __launch_bounds__(1024) void spine_msd_kernel(MsdArgs a) {
+  constexpr uint32_t D = 1u << BITS, ROW = D / 2;
+  constexpr uint32_t WORDS = 16, CHUNKS = 64, MAXROWS = kMsdMaxTiles / CHUNKS;
+  __shared__ uint32_t sumLo[WORDS][CHUNKS], sumHi[WORDS][CHUNKS], total[2 * WORDS], below[4];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t j = tid & (WORDS - 1), c = tid / WORDS;
+  const uint32_t w = blockIdx.x * WORDS + j;
+  const uint32_t rows = (a.tiles + CHUNKS - 1) / CHUNKS;  // per chunk, <= MAXROWS (the host sees to it)
+  const uint32_t r0 = c * rows;
+  uint32_t* const column = a.tileCounts + w;
+
+  // keys below this workgroup's first bucket
+  const uint32_t firstByte = (blockIdx.x * 2u * WORDS) >> (BITS - 8u);
+  uint32_t under = tid < 256u && tid < firstByte ? a.histogramTable[3u * VRDX_RADIX + tid] : 0u;
+
+  uint32_t v[MAXROWS];
+  uint32_t lo = 0, hi = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < MAXROWS; ++k) {
+    v[k] = (k < rows && r0 + k < a.tiles) ? column[(size_t)(r0 + k) * ROW] : 0u;
+    lo += v[k] & 0xFFFFu;
+    hi += v[k] >> 16;
+  }
+  sumLo[j][c] = lo;
+  sumHi[j][c] = hi;
+  if (tid < 256u) {
+    under = WaveInclusiveScan(under);
+    if ((tid & 63u) == 63u) below[tid >> 6] = under;
+  }
+  __syncthreads();
+  {
+    const uint32_t word = tid >> 6, chunk = tid & 63u;  // one wave per word
+    const uint32_t x = sumLo[word][chunk], y = sumHi[word][chunk];
+    const uint32_t ix = WaveInclusiveScan(x), iy = WaveInclusiveScan(y);
+    sumLo[word][chunk] = ix - x;
+    sumHi[word][chunk] = iy - y;
+    if (chunk == 63u) {
+      total[2 * word] = ix;
+      total[2 * word + 1] = iy;
+    }
+  }
+  __syncthreads();
+  lo = sumLo[j][c];
+  hi = sumHi[j][c];
+#pragma unroll
+  for (uint32_t k = 0; k < MAXROWS; ++k) {
+    if (k < rows && r0 + k < a.tiles) column[(size_t)(r0 + k) * ROW] = (lo & 0xFFFFu) | (hi << 16);
+    lo += v[k] & 0xFFFFu;
+    hi += v[k] >> 16;
+  }
+  if (tid < 64u) {
+    const uint32_t mine = tid < 2 * WORDS ? total[tid] : 0u;
+    const uint32_t inclusive = WaveInclusiveScan(mine);
+    if (tid < 2 * WORDS) {
+      const uint32_t d = blockIdx.x * 2u * WORDS + tid;
+      a.bucketBase[d] = below[0] + below[1] + below[2] + below[3] + inclusive - mine;
+      a.bucketCount[d] = mine;
+      if (mine > a.cap) atomicOr(a.overflowWord, 1u);
+    }
+  }
+}
+
+// ---- scatter_msd_kernel -----------------------------------------------------------------------------
+// One tile of 32768 keys: load (wave-striped), rank by the top BITS bits with packed counters, scan, positions, regroup
+// through the staging buffer -- which takes the counters' place once every wave knows its positions: 128 KiB of staging
+// and 64 KiB of counters would not fit side by side -- and out in quads like the pass kernels, boundary quads by the thread
+// that owns the run (two runs per thread here).  The tile's 2^BITS bases arrive with the keys: one row of prefixes and the
+// bucket bases, loaded first.
+template <uint32_t BITS, int KPT>
+constexpr size_t ScatterMsdLdsWords() {
+  return (size_t)1024 * KPT + (1u << BITS) + 32;
+}
+
+// KPT = 32: tiles of 32768 keys, one workgroup per CU (132-136 KiB of LDS); KPT = 16: 16384 keys, 68-72 KiB, two workgroups per
+// CU -- two independent tile lives per CU, which nothing in this kernel makes expensive (there is no per-tile chain).
+template <uint32_t BITS, int KPT, bool KV>
+__global__ __launch_bounds__(1024, (KPT <= 16 ? 8 : 4)) void scatter_msd_kernel(MsdArgs a) {
+  constexpr int THREADS = 1024, WAVES = THREADS / 64;
+  constexpr uint32_t TILE = THREADS * KPT, D = 1u << BITS, SHIFT = 32u - BITS, MASK = D - 1u, ROW = D / 2u;
+  static_assert(ROW <= (uint32_t)THREADS && WAVES * ROW <= TILE && KPT % 8 == 0, "geometry");
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  uint32_t* const sorted = smem;               // TILE: keys (then values) regrouped by digit
+  uint32_t* const counters = smem;             // WAVES x ROW packed counters; dead before the first key is staged
+  uint32_t* const tileOffset = smem + TILE;    // D: global base - tile-local base
+  uint32_t* const scanScratch = tileOffset + D;  // 32
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const uint32_t n = ElementCount(a.maxCount, a.countPtr);
+  const uint32_t tile = blockIdx.x;
+  const uint32_t tileStart = tile * TILE;
+  // (loads first, verdict second: the keys fly while the overflow word arrives)
+  const uint32_t valid = tileStart < n ? ((n - tileStart) < TILE ? (n - tileStart) : TILE) : 0u;
+  const uint32_t tileEnd = tileStart + valid;
+  const uint32_t loadBase = tileStart + wave * (KPT * 64) + lane;
+  uint32_t key[KPT];
+  LoadStriped<KPT>(a.keysCaller, loadBase, tileEnd, valid == TILE, 0xFFFFFFFFu, key);  // pad: downsweep.slang:81
+  uint32_t prefixWord = 0, base0 = 0, base1 = 0;
+  if ((uint32_t)tid < ROW) {
+    prefixWord = a.tileCounts[(size_t)tile * ROW + tid];
+    base0 = a.bucketBase[2 * tid];
+    base1 = a.bucketBase[2 * tid + 1];
+  }
+  if (*a.overflowWord != 0u) return;  // a bucket beyond the capacity: the four passes behind this launch run
+  if (tile == 0 && tid == 0) *a.planWord = 3u;  // for the launches behind this one
+  if (valid == 0) return;
+
+  uint32_t* const myRow = counters + wave * ROW;
+#pragma unroll
+  for (uint32_t i = 0; i < ROW / 256u; ++i) reinterpret_cast<u32x4*>(myRow)[lane + 64 * i] = u32x4{0u, 0u, 0u, 0u};
+  uint32_t rank[KPT / 2];  // ranks, then physical staging slots, two to a register
+  RankPacked16<KPT, false>(key, SHIFT, MASK, myRow, lane, rank);
+  ForgetDerivedValues<KPT>(key);
+  LdsBarrier();
+
+  // tile histogram, tile-local bases, every wave's first position per digit
+  const uint32_t totals = (uint32_t)tid < ROW ? ColumnTotals<ROW, WAVES>(counters, tid) : 0u;
+  const uint32_t count0 = totals & 0xFFFFu, count1 = totals >> 16;
+  const uint32_t local0 = BlockExclusiveScanAll<THREADS>(count0 + count1, scanScratch, tid);
+  const uint32_t local1 = local0 + count0;
+  if ((uint32_t)tid < ROW) {
+    ColumnBases<ROW, WAVES>(counters, tid, local0 | (local1 << 16));
+    tileOffset[2 * tid] = base0 + (prefixWord & 0xFFFFu) - local0;
+    tileOffset[2 * tid + 1] = base1 + (prefixWord >> 16) - local1;
+  }
+  LdsBarrier();
+  PositionsPacked16<KPT, TILE, false>(key, SHIFT, MASK, myRow, rank);
+  LdsBarrier();  // the counters are dead: the staging buffer takes their place
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) sorted[(rank[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = key[i];
+  LdsBarrier();
+  // key+value: the values are fetched now and land while the keys are scattered (like scatter9_kernel)
+  uint32_t val[KV ? KPT : 1];
+  if constexpr (KV) LoadStriped<KPT>(a.valuesCaller, loadBase, tileEnd, valid == TILE, 0u, val);  // pad: downsweep.slang:85
+
+  // scatter: whole single-digit quads in the main loop, the quads around a run's start by the thread that owns the run
+  constexpr int QUADS = KPT / 4;
+  constexpr int B = 4;
+  uint32_t quadDigits[KV ? QUADS : 1];  // key+value: first | last << 16 digit of every main-loop quad, for the value phase
+  uint32_t boundaryQuad[2] = {~0u, ~0u};
+  uint32_t boundaryDigits[2][2] = {{0, 0}, {0, 0}};
+  if ((uint32_t)tid < ROW) {
+    if (count0 != 0 && (local0 & 3u) != 0 && local0 < valid) boundaryQuad[0] = local0 & ~3u;
+    if (count1 != 0 && (local1 & 3u) != 0 && local1 < valid) boundaryQuad[1] = local1 & ~3u;
+  }
+  if (tid == 0 && (valid & 3u) != 0) boundaryQuad[0] = valid & ~3u;  // (digit 0 starts at 0: thread 0's first slot is free)
+  auto scatterQuads = [&](uint32_t* out, bool keysPhase) {
+#pragma unroll
+    for (int j0 = 0; j0 < QUADS; j0 += B) {
+      if (4u * (uint32_t)j0 * THREADS >= valid) break;
+      u32x4 w4[B];
+      uint32_t o[B];
+      bool whole[B];
+#pragma unroll
+      for (int b = 0; b < B; ++b) w4[b] = *reinterpret_cast<const u32x4*>(&sorted[4u * (tid + (j0 + b) * THREADS)]);
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const int j = j0 + b;
+        const uint32_t p = StagingSlot<TILE>(4u * (tid + j * THREADS));  // involution: the sorted position of the quad
+        uint32_t d0, d3;
+        if (keysPhase) {
+          d0 = w4[b][0] >> SHIFT;
+          d3 = w4[b][3] >> SHIFT;
+          if constexpr (KV) quadDigits[j] = d0 | (d3 << 16);
+        } else {
+          d0 = quadDigits[KV ? j : 0] & 0xFFFFu;
+          d3 = quadDigits[KV ? j : 0] >> 16;
+        }
+        whole[b] = p + 3 < valid && d0 == d3;
+        o[b] = tileOffset[d0] + p;
+        asm volatile("" : "+v"(o[b]));  // fetched here, for every quad: not sunk into the conditional store
+      }
+#pragma unroll
+      for (int b = 0; b < B; ++b)
+        if (whole[b]) StoreQuad(out, o[b], w4[b]);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (boundaryQuad[s] == ~0u) continue;
+      const u32x4 q = *reinterpret_cast<const u32x4*>(&sorted[StagingSlot<TILE>(boundaryQuad[s])]);
+      if (keysPhase) {
+        boundaryDigits[s][0] = (q[0] >> SHIFT) | ((q[1] >> SHIFT) << 16);
+        boundaryDigits[s][1] = (q[2] >> SHIFT) | ((q[3] >> SHIFT) << 16);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t d = (boundaryDigits[s][c / 2] >> (16 * (c % 2))) & 0xFFFFu;
+        if (boundaryQuad[s] + c < valid) StoreWord(out, tileOffset[d] + boundaryQuad[s] + c, q[c]);
+      }
+    }
+  };
+  scatterQuads(a.keysScratch, true);
+  if constexpr (KV) {
+    LdsBarrier();  // every key has left the staging buffer
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) sorted[(rank[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
+    LdsBarrier();
+    scatterQuads(a.valuesScratch, false);
+  }
+}
+
+// ---- bucket_sort2_kernel ----------------------------------------------------------------------------
+// Workgroup b sorts bucket b = [bucketBase[b], + bucketCount[b]) of the scratch arrays by the 32 - BITS bits below the
+// scatter's, in two stable passes (11 bits, then the rest) with 2048 packed counters per wave, and writes it to the same
+// range of the caller's arrays.  Keys (and values) stay in registers between the passes; the staging buffer -- up to
+// 144 KiB -- takes the counters' place inside each pass like in scatter_msd_kernel; key+value stages the values through
+// the same slots after the keys.  A wave takes only as many slots as the bucket needs (like SortInWorkgroup).
+template <int KPT>
+constexpr size_t BucketSort2LdsWords() {
+  return (size_t)1024 * KPT + 32;
+}
+
+template <uint32_t BITS, int KPT, bool KV>
+__global__ __launch_bounds__(1024) void bucket_sort2_kernel(MsdArgs a) {
+  constexpr int THREADS = 1024, WAVES = THREADS / 64;
+  constexpr uint32_t TILE = THREADS * KPT;
+  constexpr uint32_t W0 = 11u, W1 = 32u - BITS - W0;
+  constexpr uint32_t ROW = 1024;  // 2048 packed counters per wave
+  static_assert(W1 >= 1 && W1 <= 11, "two passes of at most eleven bits");
+  static_assert(TILE <= 65536 && WAVES * ROW <= TILE && KPT % 4 == 0, "packed positions; the staging buffer covers the counters");
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  uint32_t* const staged = smem;             // TILE
+  uint32_t* const counters = smem;           // WAVES x ROW, inside each pass only
+  uint32_t* const scanScratch = smem + TILE; // 32
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  if (*a.planWord != 3u) return;  // the plan does not apply: the four passes are running
+  const uint32_t myBase = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.bucketBase[blockIdx.x]);
+  const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.bucketCount[blockIdx.x]);
+  if (n == 0) return;
+  const uint32_t* const keysIn = a.keysScratch + myBase;
+  uint32_t* const keysOut = a.keysCaller + myBase;
+  const uint32_t* const valuesIn = KV ? a.valuesScratch + myBase : nullptr;
+  uint32_t* const valuesOut = KV ? a.valuesCaller + myBase : nullptr;
+
+  constexpr bool DYN = true;
+  uint32_t slots = 4u * ((n + 4u * THREADS - 1u) / (4u * THREADS));
+  slots = slots < (uint32_t)KPT ? slots : (uint32_t)KPT;
+  const uint32_t first = wave * (slots * 64) + lane;  // element i of this lane: first + 64 * i
+  {
+    // a wave whose range starts at or behind n holds nothing but pads and skips every loop over its slots (SortInWorkgroup)
+    const uint32_t waveStart = (uint32_t)wave * (slots * 64);
+    const uint32_t mine = n > waveStart ? n - waveStart : 0u;
+    const uint32_t waveSlots = 4u * ((mine + 255u) / 256u);
+    slots = waveSlots < slots ? waveSlots : slots;
+  }
+  uint32_t key[KPT];
+  uint32_t val[KV ? KPT : 1];
+  LoadStriped<KPT, false, DYN>(keysIn, first, n, false, 0xFFFFFFFFu, key, slots);
+  if constexpr (KV) LoadStriped<KPT, false, DYN>(valuesIn, first, n, false, 0u, val, slots);
+
+  uint32_t* const myRow = counters + wave * ROW;
+#pragma unroll 1
+  for (uint32_t pass = 0; pass < 2; ++pass) {
+    const uint32_t shift = pass == 0 ? 0u : W0;
+    const uint32_t mask = pass == 0 ? (1u << W0) - 1u : (1u << W1) - 1u;
+#pragma unroll
+    for (uint32_t i = 0; i < ROW / 256u; ++i) reinterpret_cast<u32x4*>(myRow)[lane + 64 * i] = u32x4{0u, 0u, 0u, 0u};
+    uint32_t rank[KPT / 2];
+    RankPacked16<KPT, DYN>(key, shift, mask, myRow, lane, rank, slots);
+    LdsBarrier();
+    uint32_t firstNow = first;  // (see SortInWorkgroup: keeps the read-back addresses out of registers across the passes)
+    asm volatile("" : "+v"(firstNow));
+    const uint32_t totals = ColumnTotals<ROW, WAVES>(counters, tid);
+    const uint32_t count0 = totals & 0xFFFFu;
+    const uint32_t local0 = BlockExclusiveScanAll<THREADS>(count0 + (totals >> 16), scanScratch + 16 * pass, tid);
+    ColumnBases<ROW, WAVES>(counters, tid, local0 | ((local0 + count0) << 16));
+    LdsBarrier();
+    PositionsPacked16<KPT, TILE, DYN>(key, shift, mask, myRow, rank, slots);
+    LdsBarrier();  // the counters are dead: the staging buffer takes their place
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
+      staged[(rank[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = key[i];
+    }
+    LdsBarrier();
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
+      key[i] = staged[StagingSlot<TILE>(firstNow + 64 * i)];
+    }
+    if constexpr (KV) {
+      LdsBarrier();
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
+        staged[(rank[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
+      }
+      LdsBarrier();
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
+        val[i] = staged[StagingSlot<TILE>(firstNow + 64 * i)];
+      }
+    }
+    LdsBarrier();  // the next pass clears its counters where the staging buffer is
+  }
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) {
+    if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
+    const uint32_t index = first + 64 * i;
+    if (index < n) {
+      keysOut[index] = key[i];
+      if constexpr (KV) valuesOut[index] = val[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // device self-check for RankAtomic's precondition
 // ---------------------------------------------------------------------------------------------
 // Every wave ranks pseudo-random digit vectors of several entropies (constant, 2, 4, 16, 256
@@ -2045,6 +2667,56 @@ __global__ __launch_bounds__(1024) void lds_order_check_kernel(uint32_t* mismatc
   }
 }
 
+// The same for RankPacked16 (MSD plan): 2048 digits in packed 16-bit counters, two digits to a word, so lanes of one
+// instruction meet on one WORD with DIFFERENT addends -- the shape the check above does not cover.  The reference ranks
+// come from eleven ballots and a non-returning add by each group's first lane (sums do not depend on any order).
+// Dynamic LDS: [16][1024] packed counters for the atomics | the same for the ballots = 128 KiB.
+__device__ __forceinline__ uint32_t OrderCheckDigit11(uint32_t tid, uint32_t wave, uint32_t slot) {
+  uint32_t x = (blockIdx.x * 1024u + tid) * 0x9E3779B9u + slot * 0x85EBCA6Bu + 0x7F4A7C15u;
+  x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+  const uint32_t mode = (blockIdx.x + wave + slot) % 7u;
+  // constant | the two halves of one word | two words | 16 values | sparse collisions | 64 neighbours | all eleven bits
+  const uint32_t mask = mode == 0 ? 0u : mode == 1 ? 1u : mode == 2 ? 3u : mode == 3 ? 15u : mode == 4 ? 0x421u : mode == 5 ? 63u : 2047u;
+  return ((x & mask) + (mode == 5 ? 0x300u : 0u)) & 2047u;
+}
+
+__global__ __launch_bounds__(1024) void lds_order_check_packed_kernel(uint32_t* mismatches, uint32_t* sticky) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t* const rowA = smem + wave * 1024;
+  uint32_t* const rowB = smem + (16 + wave) * 1024;
+  for (int i = lane; i < 1024; i += 64) rowA[i] = rowB[i] = 0;  // wave-private rows: no barrier needed
+  uint32_t bad = 0;
+#pragma unroll 1
+  for (uint32_t round = 0; round < 4; ++round) {
+    uint32_t key[16], got[8];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) key[i] = OrderCheckDigit11(tid, wave, round * 16 + i);
+    RankPacked16<16, false>(key, 0, 2047u, rowA, lane, got);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const uint32_t d = key[i];
+      uint64_t same = ~0ull;
+#pragma unroll
+      for (int b = 0; b < 11; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t ballot = __ballot(bit);
+        same &= bit ? ballot : ~ballot;
+      }
+      const uint32_t below = LanesBelow(same);
+      const uint32_t sh = (d & 1u) * 16u;
+      const uint32_t prior = (__hip_atomic_load(&rowB[d >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> sh) & 0xFFFFu;
+      if (below == 0)
+        (void)__hip_atomic_fetch_add(&rowB[d >> 1], (uint32_t)__popcll(same) << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      bad += ((got[i / 2] >> (16 * (i % 2))) & 0xFFFFu) != prior + below;
+    }
+  }
+  if (bad != 0) {
+    if (mismatches != nullptr) atomicAdd(mismatches, bad);
+    if (sticky != nullptr) atomicOr(sticky, 2u);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // a kernel of KNOWN duration, for calibrating what a pair of HIP events adds to the kernel between them
 // ---------------------------------------------------------------------------------------------
@@ -2068,6 +2740,8 @@ __global__ __launch_bounds__(64) void spin_kernel(unsigned long long* out, uint3
 // ---------------------------------------------------------------------------------------------
 // Every launcher returns the hipError_t of ITS launch (hipLaunchKernel), so that the recorder never has to consult
 // the calling thread's sticky last-error state, which an unrelated earlier failure may have set.
+constexpr size_t kOrderCheckPackedLdsBytes = 2 * 16 * 1024 * sizeof(uint32_t);
+
 template <typename... Args>
 static hipError_t Launch(const void* kernel, uint32_t grid, uint32_t block, size_t ldsBytes, hipStream_t stream,
                          Args... args) {
@@ -2197,6 +2871,9 @@ hipError_t LdsOrderCheck(bool* laneOrdered) {
   e = hipMemset(d, 0, sizeof(uint32_t));
   uint32_t* const noSticky = nullptr;
   if (e == hipSuccess) e = Launch(reinterpret_cast<const void*>(&lds_order_check_kernel), 512, 1024, 0, nullptr, d, noSticky);
+  // the packed-counter shape of the MSD plan: two digits to a word (PrepareMsd has raised this kernel's LDS limit)
+  if (e == hipSuccess)
+    e = Launch(reinterpret_cast<const void*>(&lds_order_check_packed_kernel), 256, 1024, kOrderCheckPackedLdsBytes, nullptr, d, noSticky);
   if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof(uint32_t), hipMemcpyDeviceToHost);
   (void)hipFree(d);
   if (e == hipSuccess) *laneOrdered = h == 0;
@@ -2205,7 +2882,9 @@ hipError_t LdsOrderCheck(bool* laneOrdered) {
 
 hipError_t LaunchLdsOrderRecheck(hipStream_t stream, uint32_t* sticky) {
   uint32_t* const noCount = nullptr;
-  return Launch(reinterpret_cast<const void*>(&lds_order_check_kernel), 8, 1024, 0, stream, noCount, sticky);
+  const hipError_t e = Launch(reinterpret_cast<const void*>(&lds_order_check_kernel), 8, 1024, 0, stream, noCount, sticky);
+  if (e != hipSuccess) return e;
+  return Launch(reinterpret_cast<const void*>(&lds_order_check_packed_kernel), 8, 1024, kOrderCheckPackedLdsBytes, stream, noCount, sticky);
 }
 
 hipError_t LaunchSpin(hipStream_t stream, unsigned long long* out, uint32_t ticks) {
@@ -2359,6 +3038,107 @@ hipError_t LaunchBucketSort9(hipStream_t stream, bool keyValue, const BucketSort
   const void* const kernel = keyValue ? reinterpret_cast<const void*>(&bucket_sort_kernel<1024, 32, true, true, 512>)
                                       : reinterpret_cast<const void*>(&bucket_sort_kernel<1024, 32, false, true, 512>);
   return Launch(kernel, 512, 1024, lds, stream, args);
+}
+
+// ---- MSD plan -----------------------------------------------------------------------------------------
+template <uint32_t BITS>
+static hipError_t PrepareMsdBits() {
+  const struct {
+    const void* fn;
+    size_t bytes;
+  } kernels[] = {
+      {reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, BITS, 2>), HistMsdLdsBytes(kHistCopies)},
+      {reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, BITS, 2>), HistMsdLdsBytes(kHistCopiesLarge)},
+      {reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, BITS, 1>), HistMsdLdsBytes(kHistCopies)},
+      {reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, BITS, 1>), HistMsdLdsBytes(kHistCopiesLarge)},
+      {reinterpret_cast<const void*>(&scatter_msd_kernel<BITS, 32, false>), ScatterMsdLdsWords<BITS, 32>() * 4},
+      {reinterpret_cast<const void*>(&scatter_msd_kernel<BITS, 32, true>), ScatterMsdLdsWords<BITS, 32>() * 4},
+      {reinterpret_cast<const void*>(&scatter_msd_kernel<BITS, 16, false>), ScatterMsdLdsWords<BITS, 16>() * 4},
+      {reinterpret_cast<const void*>(&scatter_msd_kernel<BITS, 16, true>), ScatterMsdLdsWords<BITS, 16>() * 4},
+      {reinterpret_cast<const void*>(&bucket_sort2_kernel<BITS, kMsdCapKeys / 1024, false>), BucketSort2LdsWords<kMsdCapKeys / 1024>() * 4},
+      {reinterpret_cast<const void*>(&bucket_sort2_kernel<BITS, kMsdCapKeyValue / 1024, true>), BucketSort2LdsWords<kMsdCapKeyValue / 1024>() * 4},
+  };
+  for (const auto& k : kernels) {
+    const hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.bytes);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+hipError_t PrepareMsd() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_order_check_packed_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOrderCheckPackedLdsBytes);
+  if (e == hipSuccess) e = PrepareMsdBits<10>();
+  if (e == hipSuccess) e = PrepareMsdBits<11>();
+  return e;
+}
+
+hipError_t LaunchHistogramMsd(hipStream_t stream, uint32_t grid, const uint32_t* keys, uint32_t maxCount,
+                              const uint32_t* countPtr, uint32_t* globalHistogram, uint32_t* tickets, void* statusClear,
+                              uint32_t statusClearBytes, uint32_t* tileCounts, uint32_t tiles, uint32_t bits,
+                              uint32_t tileKeys) {
+  u32x4* const clear = reinterpret_cast<u32x4*>(statusClear);
+  const uint32_t vecs = statusClearBytes / 16u;
+  const bool many = maxCount >= kHistManyCopiesFrom;
+  const void* kernel;
+  if (tileKeys != 16384u && tileKeys != 32768u) return hipErrorInvalidValue;
+  const bool two = tileKeys == 32768u;
+  if (bits == 10)
+    kernel = many ? (two ? reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, 10, 2>)
+                         : reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, 10, 1>))
+                  : (two ? reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, 10, 2>)
+                         : reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, 10, 1>));
+  else if (bits == 11)
+    kernel = many ? (two ? reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, 11, 2>)
+                         : reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, 11, 1>))
+                  : (two ? reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, 11, 2>)
+                         : reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, 11, 1>));
+  else
+    return hipErrorInvalidValue;
+  return Launch(kernel, grid, kHistThreads, HistMsdLdsBytes(many ? kHistCopiesLarge : kHistCopies), stream, keys, maxCount,
+                countPtr, globalHistogram, tickets, clear, vecs, tileCounts, tiles);
+}
+
+hipError_t LaunchSpineMsd(hipStream_t stream, const MsdArgs& args) {
+  if (args.tiles > kMsdMaxTiles) return hipErrorInvalidValue;
+  if (args.bits == 10) return Launch(reinterpret_cast<const void*>(&spine_msd_kernel<10>), 512 / 16, 1024, 0, stream, args);
+  if (args.bits == 11) return Launch(reinterpret_cast<const void*>(&spine_msd_kernel<11>), 1024 / 16, 1024, 0, stream, args);
+  return hipErrorInvalidValue;
+}
+
+template <uint32_t BITS>
+static hipError_t LaunchScatterMsdBits(hipStream_t stream, bool keyValue, const MsdArgs& args) {
+  if (args.tileKeys == 32768u)
+    return Launch(keyValue ? reinterpret_cast<const void*>(&scatter_msd_kernel<BITS, 32, true>)
+                           : reinterpret_cast<const void*>(&scatter_msd_kernel<BITS, 32, false>),
+                  args.tiles, 1024, ScatterMsdLdsWords<BITS, 32>() * 4, stream, args);
+  if (args.tileKeys == 16384u)
+    return Launch(keyValue ? reinterpret_cast<const void*>(&scatter_msd_kernel<BITS, 16, true>)
+                           : reinterpret_cast<const void*>(&scatter_msd_kernel<BITS, 16, false>),
+                  args.tiles, 1024, ScatterMsdLdsWords<BITS, 16>() * 4, stream, args);
+  return hipErrorInvalidValue;
+}
+
+hipError_t LaunchScatterMsd(hipStream_t stream, bool keyValue, const MsdArgs& args) {
+  if (args.bits == 10) return LaunchScatterMsdBits<10>(stream, keyValue, args);
+  if (args.bits == 11) return LaunchScatterMsdBits<11>(stream, keyValue, args);
+  return hipErrorInvalidValue;
+}
+
+hipError_t LaunchBucketSort2(hipStream_t stream, bool keyValue, const MsdArgs& args) {
+  constexpr int kKeys = kMsdCapKeys / 1024, kPairs = kMsdCapKeyValue / 1024;
+  if (args.cap != (keyValue ? kMsdCapKeyValue : kMsdCapKeys)) return hipErrorInvalidValue;
+  const void* kernel;
+  if (args.bits == 10)
+    kernel = keyValue ? reinterpret_cast<const void*>(&bucket_sort2_kernel<10, kPairs, true>)
+                      : reinterpret_cast<const void*>(&bucket_sort2_kernel<10, kKeys, false>);
+  else if (args.bits == 11)
+    kernel = keyValue ? reinterpret_cast<const void*>(&bucket_sort2_kernel<11, kPairs, true>)
+                      : reinterpret_cast<const void*>(&bucket_sort2_kernel<11, kKeys, false>);
+  else
+    return hipErrorInvalidValue;
+  const size_t lds = (keyValue ? BucketSort2LdsWords<kPairs>() : BucketSort2LdsWords<kKeys>()) * 4;
+  return Launch(kernel, 1u << args.bits, 1024, lds, stream, args);
 }
 
 hipError_t LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool keyValue, bool atomicRank,

@@ -69,6 +69,9 @@
 // word 1 of the storage (zeroed with the rest of the prefix before every sort): the hybrid plan's verdict, written by
 // launch 0 -- 1 = the plan applies (launches 1-3 return at once), 2 = the four passes run (the bucket launch returns)
 #define VRDX_OFF_PLAN 4u
+// word 2 (zeroed likewise): the MSD plan's spine raises it when a bucket exceeds the capacity -- the plan's scatter and
+// bucket launches then return and the four passes run (vrdx_kernels.hip, "MSD plan")
+#define VRDX_OFF_MSD_OVERFLOW 8u
 
 #ifdef __cplusplus
 namespace vrdx {
@@ -97,12 +100,16 @@ struct StorageLayout {
   uint64_t top9Offset;       // uint32[512]: counts of the keys' top nine bits (nine-bit hybrid plan only), behind the table
   uint64_t status9Offset;    // uint32[tiles9 - 1][512]: status rows of scatter9_kernel (nine-bit hybrid plan only)
   uint64_t status9Bytes;
+  uint64_t msdCountsOffset;  // MSD plan only: uint16[msdTiles][2^msdBits] per-tile counts / prefixes of the keys' top bits,
+  uint64_t msdCountsBytes;   //   in front of status region 0 like the nine-bit plan's rows (the two plans exclude each other)
+  uint64_t msdBucketOffset;  // MSD plan only: uint32[2][2^msdBits] bucket bases, then bucket sizes
   uint64_t statusOffset;     // uint32[2][rows + blockRows][256]: tile rows, then block rows, per region
   uint64_t statusRows;       // tile rows per region = max(tiles - 1, 0)
   uint64_t blockRows;        // block-sum rows per region (one per 32 tiles); 0 = classic look-back
   uint64_t regionBytes;      // (statusRows + blockRows) KiB
   uint64_t clearBytes;       // bytes from storageOffset zeroed by the fill in front of every sort: header + global histogram
-  uint64_t statusClearBytes; // status region 0, zeroed by the histogram kernel (pass 0 is its first reader)
+  uint64_t statusClearOffset; // what the histogram kernel zeroes: the nine-bit plan's rows (if any) and status region 0
+  uint64_t statusClearBytes;  // (pass 0 is its first reader)
   uint64_t inoutOffset;      // keys scratch
   uint64_t valuesOffset;     // values scratch (KV only)
   uint64_t keysOnlySize;     // total storage, keys-only
@@ -115,8 +122,10 @@ struct StorageLayout {
 // tiles9: tiles of scatter9_kernel when the nine-bit hybrid plan is recorded next to the passes (0: it is not): the 512
 // nine-bit counts follow the histogram table (one fill clears both) and that launch's status rows, 2 KiB each, sit in
 // front of status region 0 (the histogram kernel clears both in one sweep).
+// msdBits / msdTiles: the MSD plan is recorded in front of the passes (10 | 11 bits, tiles of 32768 keys; 0: it is not).
 static inline StorageLayout MakeLayout(uint32_t maxElementCount, uint32_t align, uint64_t tiles,
-                                       uint64_t storageAddress = 0, bool blockSums = false, uint64_t tiles9 = 0) {
+                                       uint64_t storageAddress = 0, bool blockSums = false, uint64_t tiles9 = 0,
+                                       uint32_t msdBits = 0, uint64_t msdTiles = 0) {
   StorageLayout l;
   const uint64_t elementCountSize = Align((uint32_t)sizeof(uint32_t), align);
   const uint64_t histogramSize = HistogramSize(maxElementCount, align);
@@ -128,14 +137,18 @@ static inline StorageLayout MakeLayout(uint32_t maxElementCount, uint32_t align,
   const uint64_t tableEnd = l.top9Offset + (tiles9 != 0 ? 512 * sizeof(uint32_t) : 0);
   l.status9Offset = tableEnd + ((0 - (storageAddress + tableEnd)) & 127u);
   l.status9Bytes = tiles9 > 1 ? (tiles9 - 1) * 512 * sizeof(uint32_t) : 0;
-  l.statusOffset = l.status9Offset + l.status9Bytes;
+  l.msdCountsOffset = l.status9Offset + l.status9Bytes;
+  l.msdCountsBytes = msdBits != 0 ? msdTiles * ((uint64_t)2 << msdBits) : 0;  // 16 bits per (tile, bucket)
+  l.msdBucketOffset = l.msdCountsOffset + l.msdCountsBytes;
+  l.statusOffset = l.msdBucketOffset + (msdBits != 0 ? ((uint64_t)8 << msdBits) : 0);  // (a multiple of 128 bytes like the rest)
   l.statusRows = tiles > 0 ? tiles - 1 : 0;
   l.blockRows = blockSums ? (tiles + VRDX_BLOCK_TILES - 1) / VRDX_BLOCK_TILES : 0;
   l.regionBytes = (l.statusRows + l.blockRows) * VRDX_RADIX * sizeof(uint32_t);
   // count + plan word + failure word + global histogram: what the histogram kernel's atomics and the passes' first
   // reads need zeroed BEFORE that kernel starts; status region 0 is zeroed by the histogram kernel itself
   l.clearBytes = tableEnd;
-  l.statusClearBytes = l.status9Bytes + l.regionBytes;  // from status9Offset
+  l.statusClearOffset = tiles9 != 0 ? l.status9Offset : l.statusOffset;
+  l.statusClearBytes = l.status9Bytes + l.regionBytes;
   l.ticketOffset = l.statusOffset + 2 * l.regionBytes;
   l.inoutOffset = l.ticketOffset + 128;
   l.valuesOffset = l.inoutOffset + (((uint64_t)maxElementCount * sizeof(uint32_t) + 127u) & ~(uint64_t)127u);
@@ -180,7 +193,8 @@ struct TilePlan {
 
 // Block sums pay when all tiles of a pass start together, i.e. in sorts of one round (BlockPrefix in vrdx_kernels.hip).
 static inline bool BlockSumsApply(uint32_t tiles, uint32_t cus, uint32_t tileKeys) {
-  return tileKeys >= 32768u && tiles >= VRDX_BLOCK_PREFIX_MIN_TILES && tiles <= cus;
+  // (BlockPrefix adds up at most 2 x 16 block rows: 32 blocks of VRDX_BLOCK_TILES tiles, whatever the CU count)
+  return tileKeys >= 32768u && tiles >= VRDX_BLOCK_PREFIX_MIN_TILES && tiles <= cus && tiles <= 32u * VRDX_BLOCK_TILES;
 }
 
 // threads / keysPerThread / subTiles: the kernel's geometry; splitForms: its forms with run-time slot counts exist;
