@@ -3,13 +3,23 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--log2n 25]
 
-A "step" is one complete sort (histogram + 4 onesweep passes) of one batch of synthetic input:
+A "step" is one complete sort (whatever plan the library records for that size: at 2^25 the MSD plan --
+histogram, spine, scatter by the top ten bits, one in-LDS sort per bucket -- with the four onesweep passes
+behind it as the device-side fallback) of one batch of synthetic input:
 N = 2^25 uniform-random u32 keys (BASELINE.json configs[1]); the key+value figure (configs[2]) is
 measured the same way and reported in the same JSON line under "key_value".  Inputs are resident
 in HBM before the timed region starts: every step sorts its own pre-generated array in place, so
 the timed region holds exactly K sorts and nothing else (the reference likewise excludes upload
 and read-back: bench/vulkan_benchmark.cc:267-290,306-316, and uses fresh data per run:
 bench/bench.cc:83-84).
+
+Behind the headline region (rank 0 of a 1-GPU run only) the line also carries the reference's size curve
+(bench/bench.cc:17-20,161-203: 1 warm-up + 10 timed runs on fresh data, median GPU time) at N = 2^18 ... 2^25
+for keys-only and key+value under "sweep", and one HBM-resident point at N = 2^27 (far past the 256 MiB
+Infinity Cache) under "hbm_resident".
+
+Host memory is O(1) in --steps: the input streams are generated a few at a time on host threads, uploaded
+and freed; the pristine copies live on the device.
 
 With --gpus N > 1 this is the batched many-arrays variant (BASELINE.json configs[4]): one rank per
 GPU, every rank sorts its own independent arrays through vulkan_radix_sort_amd.batched
@@ -45,6 +55,7 @@ def parse_args():
     p.add_argument("--warmup", type=int, default=1)    # bench/bench.cc:15 kWarmupRuns
     p.add_argument("--log2n", type=int, default=25)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-sweep", action="store_true")   # only the headline region and the roofline
     return p.parse_args()
 
 
@@ -54,7 +65,9 @@ def reference_stream(seed, n):
     like std::mt19937 does and hands out the raw 32-bit words for the full range (checked against the reference's
     generator by tests/test_oracle.py::test_bench_input_stream_is_the_reference_generator)."""
     import numpy as np
-    raw = np.random.RandomState(seed).randint(0, 1 << 32, size=2 * n, dtype=np.uint64).astype(np.uint32)
+    # (dtype uint32 with the full range hands out the raw words directly: the same stream as the uint64 detour of
+    # earlier rounds, twenty times faster -- 0.36 s instead of 7 s per 2^26 words)
+    raw = np.random.RandomState(seed).randint(0, 1 << 32, size=2 * n, dtype=np.uint32)
     return raw[:n], raw[n:]
 
 
@@ -68,20 +81,35 @@ def random_u32(torch, n, seed, device):
     return to_device(torch, reference_stream(seed, n)[0], device)
 
 
-def host_streams(n, steps, warmup):
-    """The inputs of one rank, generated ONCE on the host for both the keys-only and the key+value measurement:
-    warm-up | the K timed steps | K more, each bracketed by events.  Seeds 1, 2, ... like the reference's runs
-    (bench/bench.cc:83-84); other ranks continue the sequence."""
-    total = warmup + 2 * steps
-    seed0 = 1 + total * int(os.environ.get("RANK", "0"))
-    return [reference_stream(seed0 + i, n) for i in range(total)]
+GENERATOR_THREADS = 4   # streams in flight on the host at a time: 4 x 256 MiB at N = 2^25
 
 
-def timed_sorts(torch, dist, executor, streams, n, steps, warmup, key_value, device, distributed):
+def upload_streams(torch, n, seeds, device):
+    """Device-resident pristine copies of the reference streams of `seeds`: (keys tensors, values tensors).
+    Generated GENERATOR_THREADS at a time on host threads (numpy's generator releases the GIL), uploaded and freed
+    at once, so the host holds at most that many streams whatever --steps is (the round-4 line kept every step's
+    input on the host: 11 GiB and half a minute per rank at the driver's --steps 20 --warmup 5)."""
+    from concurrent.futures import ThreadPoolExecutor
+    keys, values = [], []
+    with ThreadPoolExecutor(GENERATOR_THREADS) as pool:
+        for lo in range(0, len(seeds), GENERATOR_THREADS):
+            for k, v in pool.map(lambda seed: reference_stream(seed, n), seeds[lo:lo + GENERATOR_THREADS]):
+                keys.append(to_device(torch, k, device))
+                values.append(to_device(torch, v, device))
+                del k, v
+    return keys, values
+
+
+def timed_sorts(torch, dist, executor, pristine, n, steps, warmup, key_value, device, distributed):
     """Returns (wall_seconds_for_K_steps_max_over_ranks, per-step gpu ms list of this rank).
-    Every sort goes through the batched front end's per-GPU executor (one array per step and rank)."""
-    keys = [to_device(torch, k, device) for k, _ in streams]
-    values = [to_device(torch, v, device) for _, v in streams] if key_value else None
+    Every sort goes through the batched front end's per-GPU executor (one array per step and rank).
+    pristine = (keys, values) device tensors, one pair per step: the keys-only measurement sorts device-side copies,
+    the key+value measurement (which runs last) the pristine arrays themselves."""
+    total = warmup + 2 * steps
+    if key_value:
+        keys, values = pristine[0][:total], pristine[1][:total]
+    else:
+        keys, values = [k.clone() for k in pristine[0][:total]], None
 
     def one(i):
         executor.enqueue([(keys[i], values[i] if key_value else None)])  # vrdxCmdSort[KeyValue]: never blocks
@@ -127,19 +155,24 @@ def timed_sorts(torch, dist, executor, streams, n, steps, warmup, key_value, dev
     return elapsed, per_step_ms
 
 
-def stage_profile(torch, sorter, n, key_value, device, repeats=5):
-    """Per-kernel event intervals from the 15-slot timestamp contract (HIP events on the sort's own stream): returns
-    (histogram_ms, mean onesweep launch ms) AS STAMPED, i.e. each including one event record (main() subtracts the
-    calibrated cost of that, vrdxHipEventOverheadNs, to get kernel time).  The stamped sort runs right BEHIND another
-    sort of a different array, like every sort of the timed region does: a kernel is charged for the write-back of what
-    the kernel before it has just written (the histogram takes 30 us after an idle gap and
-    40-44 us behind a sort), and with the stream busy the host's enqueue latency stays out of the stamps."""
+def stage_profile(torch, sorter, pristine, n, key_value, device, repeats=5):
+    """Per-kernel event intervals from the 15-slot timestamp contract (HIP events on the sort's own stream) AS
+    STAMPED, i.e. each including one event record (main() subtracts the calibrated cost of that,
+    vrdxHipEventOverheadNs, to get kernel time).  Returns a dict of mean intervals in ms:
+      the MSD plan      {"histogram", "spine", "scatter", "bucket", "fallback"}  (slots 1-2, 2-3, 3-4, 4-5, 5-14: the
+                        four launches of the fallback, which return on the plan's verdict)
+      the four passes   {"histogram", "sweep"}  (slots 1-2 and the mean of the four downsweep intervals)
+    The stamped sort runs right BEHIND another sort of a different array, like every sort of the timed region does: a
+    kernel is charged for the write-back of what the kernel before it has just written, and with
+    the stream busy the host's enqueue latency stays out of the stamps.  pristine: device-resident (keys, values)
+    lists of at least 2 * (repeats + 1) arrays, copied on the device for every run."""
     import vulkan_radix_sort_amd as vrdx
     stream = torch.cuda.current_stream().cuda_stream
     req = sorter.key_value_storage_requirements(n) if key_value else sorter.storage_requirements(n)
     storage = torch.empty(req.size, dtype=torch.uint8, device=device)
     pool = vrdx.QueryPool(15)
-    hist, sweep = [], []
+    msd = sorter.describe_plan(n, key_value).name == "msd"
+    acc = {}
 
     def record(keys, values, query_pool):
         if key_value:
@@ -150,9 +183,9 @@ def stage_profile(torch, sorter, n, key_value, device, repeats=5):
 
     for r in range(repeats + 1):
         arrays = []
-        for seed in (77 + 2 * r, 78 + 2 * r):
-            k, v = reference_stream(seed, n)
-            arrays.append((to_device(torch, k, device), to_device(torch, v, device) if key_value else None))
+        for i in (2 * r, 2 * r + 1):
+            i %= len(pristine[0])
+            arrays.append((pristine[0][i][:n].clone(), pristine[1][i][:n].clone() if key_value else None))
         torch.cuda.synchronize()
         record(arrays[0][0], arrays[0][1], None)   # the sort in front
         record(arrays[1][0], arrays[1][1], pool)   # the stamped one
@@ -160,10 +193,89 @@ def stage_profile(torch, sorter, n, key_value, device, repeats=5):
         ts = pool.results_ns()
         if r == 0:
             continue
-        hist.append((ts[2] - ts[1]) / 1e6)
-        sweep += [(ts[4 + 3 * p] - ts[3 + 3 * p]) / 1e6 for p in range(4)]
+        if msd:
+            parts = {"histogram": ts[2] - ts[1], "spine": ts[3] - ts[2], "scatter": ts[4] - ts[3],
+                     "bucket": ts[5] - ts[4], "fallback": ts[14] - ts[5]}
+        else:
+            parts = {"histogram": ts[2] - ts[1],
+                     "sweep": sum(ts[4 + 3 * p] - ts[3 + 3 * p] for p in range(4)) / 4.0}
+        for name, ns in parts.items():
+            acc.setdefault(name, []).append(ns / 1e6)
     pool.destroy()
-    return sum(hist) / len(hist), sum(sweep) / len(sweep)
+    return {name: sum(v) / len(v) for name, v in acc.items()}
+
+
+def size_curve(torch, executor, sorter, pristine, device, log2_sizes, runs=11):
+    """The reference's size curve (bench/bench.cc:15-20,66-112: 1 warm-up + 10 timed runs on fresh data per size, median)
+    for keys-only and key+value: GPU time between two events on the sort's stream around the sort, one sort at a
+    time, upload excluded (the data are device-side copies of prefixes of the pristine mt19937 streams: the first n
+    outputs of std::mt19937(seed) are exactly DataGenerator(seed)'s keys).  hbm_fraction = the HBM bytes of the plan
+    the library records for that size (vrdxHipDescribePlan) over the median time, against the 8 TB/s peak."""
+    points = []
+    for lg in log2_sizes:
+        n = 1 << lg
+        point = {"log2n": lg, "n": n}
+        for kv in (False, True):
+            ms = []
+            for r in range(runs):
+                src = r % len(pristine[0])
+                k = pristine[0][src][:n].clone()
+                v = pristine[1][src][:n].clone() if kv else None
+                start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                start.record()
+                executor.enqueue([(k, v)])
+                end.record()
+                torch.cuda.synchronize()
+                if r > 0:
+                    ms.append(start.elapsed_time(end))
+            med = sorted(ms)[len(ms) // 2]
+            plan = sorter.describe_plan(n, kv)
+            point["key_value" if kv else "keys"] = {
+                "gpu_ms": med, "gitems_per_s": n / (med * 1e-3) / 1e9, "plan": plan.name,
+                "bytes_per_item": int(plan.bytesPerElement),
+                "hbm_fraction": plan.bytesPerElement * n / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        points.append(point)
+    status = executor.finish()
+    if status != 0:
+        raise RuntimeError(f"sorter status 0x{status:08x} in the size curve")
+    return points
+
+
+def hbm_resident_point(torch, executor, sorter, pristine, device, lg=27, runs=6):
+    """One point far past the 256 MiB Infinity Cache: N = 2^27 (keys-only 36 B x 2^27 = 4.8 GB of traffic with the four
+    passes), keys = the concatenation of four pristine mt19937 streams.  Same protocol as the curve (1 + 5 runs)."""
+    n = 1 << lg
+    parts = n // pristine[0][0].numel()
+    if parts < 1 or parts > len(pristine[0]):
+        return None
+    base_k = torch.cat(pristine[0][:parts])
+    base_v = torch.cat(pristine[1][:parts])
+    out = {"log2n": lg, "n": n, "data": f"concatenation of {parts} std::mt19937 streams"}
+    for kv in (False, True):
+        ms = []
+        for r in range(runs):
+            k = base_k.clone()
+            v = base_v.clone() if kv else None
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            start.record()
+            executor.enqueue([(k, v)])
+            end.record()
+            torch.cuda.synchronize()
+            if r > 0:
+                ms.append(start.elapsed_time(end))
+            del k, v
+        med = sorted(ms)[len(ms) // 2]
+        plan = sorter.describe_plan(n, kv)
+        out["key_value" if kv else "keys"] = {
+            "gpu_ms": med, "gitems_per_s": n / (med * 1e-3) / 1e9, "plan": plan.name,
+            "bytes_per_item": int(plan.bytesPerElement),
+            "hbm_fraction": plan.bytesPerElement * n / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    status = executor.finish()
+    if status != 0:
+        raise RuntimeError(f"sorter status 0x{status:08x} at N = 2^{lg}")
+    return out
 
 
 def cpu_baseline(n):
@@ -245,6 +357,19 @@ def committed_rocprof_averages(version):
     stats["matches_this_build"] = (stats.get("kernel_source_sha256") == kernel_source_digest()
                                    and stats.get("library") == version)
     return stats
+
+
+def committed_ceiling():
+    """What fraction of the HBM peak the pass-shaped kernels can reach in this formulation, from the ablation run
+    committed under profiles/ (tools/r05/ceiling.sh -> profiles/r05_ceiling.json), with the file it comes from."""
+    path = os.path.join(ROOT, "profiles", "r05_ceiling.json")
+    try:
+        with open(path) as f:
+            c = json.load(f)
+    except (OSError, ValueError):
+        return None
+    c["source"] = "profiles/r05_ceiling.json"
+    return c
 
 
 def kernel_source_digest():
@@ -337,12 +462,21 @@ def main():
     sorter = executor.sorter
     batch = BatchedSorter(executor=executor)
 
-    streams = host_streams(n, args.steps, args.warmup)
-    wall_keys, steps_keys = timed_sorts(torch, dist, executor, streams, n, args.steps, args.warmup, False, device, distributed)
-    wall_kv, steps_kv = timed_sorts(torch, dist, executor, streams, n, args.steps, args.warmup, True, device, distributed)
-    del streams
-    hist_stamped_ms, sweep_stamped_ms = stage_profile(torch, sorter, n, False, device)
-    hist_kv_stamped_ms, sweep_kv_stamped_ms = stage_profile(torch, sorter, n, True, device)
+    # Inputs: seeds 1, 2, ... like the reference's runs (bench/bench.cc:83-84), other ranks continue the sequence;
+    # warm-up | the K timed steps | K more, each bracketed by events -- and, on the rank that reports the curve,
+    # CURVE_STREAMS more that are only ever copied from (size curve, stage profile, the 2^27 point).
+    total = args.warmup + 2 * args.steps
+    extras = rank == 0 and n_gpus == 1
+    CURVE_STREAMS = 11
+    seed0 = 1 + (total + CURVE_STREAMS) * rank
+    t_setup = time.perf_counter()
+    pristine = upload_streams(torch, n, list(range(seed0, seed0 + total + (CURVE_STREAMS if extras else 2))), device)
+    setup_s = time.perf_counter() - t_setup
+    fresh = (pristine[0][total:], pristine[1][total:])   # never sorted in place
+    wall_keys, steps_keys = timed_sorts(torch, dist, executor, pristine, n, args.steps, args.warmup, False, device, distributed)
+    wall_kv, steps_kv = timed_sorts(torch, dist, executor, pristine, n, args.steps, args.warmup, True, device, distributed)
+    stamped_keys = stage_profile(torch, sorter, fresh, n, False, device, repeats=5 if extras else 1)
+    stamped_kv = stage_profile(torch, sorter, fresh, n, True, device, repeats=5 if extras else 1)
     # ONE definition of a launch duration on this line: the event interval around the kernel minus what a pair of event
     # records adds to a kernel of known duration on this stream (vrdxHipEventOverheadNs: a kernel that times itself
     # with the device's wall clock, bracketed the same way, median of eight) = kernel time, which is what rocprofv3
@@ -354,10 +488,8 @@ def main():
     except vrdx.VrdxError:   # the calibration kernel could not run: report the raw intervals and say so
         overhead_ms = 0.0
         source = "HIP events on the sort's stream (15-slot timestamp contract), UNCALIBRATED: includes one event record"
-    hist_ms, sweep_ms = hist_stamped_ms - overhead_ms, sweep_stamped_ms - overhead_ms
-    hist_kv_ms, sweep_kv_ms = hist_kv_stamped_ms - overhead_ms, sweep_kv_stamped_ms - overhead_ms
     # end-of-batch record of every rank (the batched variant's only collective; 24 bytes per rank)
-    records = batch.gather(0, int(wall_kv * 1e9), (args.warmup + 2 * args.steps) * n)
+    records = batch.gather(0, int(wall_kv * 1e9), total * n)
 
     def median(xs):
         s = sorted(xs)
@@ -366,48 +498,86 @@ def main():
     value_keys = n_gpus * args.steps * n / wall_keys / 1e9
     value_kv = n_gpus * args.steps * n / wall_kv / 1e9
     med_keys_ms, med_kv_ms = median(steps_keys), median(steps_kv)
-
-    # dominant kernel: onesweep_kernel (4 launches per sort); algorithmic bytes per launch =
-    # 8 B/key (4 read + 4 write) x N   [key+value: 16 B/pair x N]
-    sweep_bytes = 8.0 * n
-    achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
     version = vrdx.version_string()
     pmc = latest_pmc_traffic(version)
-    roofline = {
-        "bound": "hbm", "kernel": kernel_name(version, "keys"), "achieved": achieved, "peak": HBM_PEAK_GBPS,
-        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-        "traffic": (pmc or {}).get("onesweep_keys_bytes_per_launch"),
-        "algorithmic_bytes_per_launch": sweep_bytes, "avg_launch_ms": sweep_ms,
-        "stamped_launch_ms": sweep_stamped_ms, "event_overhead_ms": overhead_ms,
-        "launch_time_source": source,
-        "histogram_kernel": {"avg_launch_ms": hist_ms, "stamped_launch_ms": hist_stamped_ms,
-                             "achieved": 4.0 * n / (hist_ms * 1e-3) / 1e9,
-                             "frac": 4.0 * n / (hist_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                             "algorithmic_bytes_per_launch": 4.0 * n},
-        "whole_sort": {"algorithmic_bytes": KEYS_BYTES_PER_ITEM * n,
-                       "achieved": KEYS_BYTES_PER_ITEM * n / (med_keys_ms * 1e-3) / 1e9,
-                       "frac": KEYS_BYTES_PER_ITEM * n / (med_keys_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
-        "key_value": {"kernel": kernel_name(version, "key-value"), "avg_launch_ms": sweep_kv_ms,
-                      "stamped_launch_ms": sweep_kv_stamped_ms,
-                      "achieved": 16.0 * n / (sweep_kv_ms * 1e-3) / 1e9,
-                      "frac": 16.0 * n / (sweep_kv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                      "whole_sort_achieved": KV_BYTES_PER_ITEM * n / (med_kv_ms * 1e-3) / 1e9,
-                      "whole_sort_frac": KV_BYTES_PER_ITEM * n / (med_kv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
-    }
+    box = os.uname().nodename
 
+    def kernels_of(stamped, key_value):
+        """Per-kernel entries of one mode: duration (stamped and calibrated), algorithmic bytes, achieved rate."""
+        plan = sorter.describe_plan(n, key_value)
+        item = 8.0 if key_value else 4.0   # bytes of one element (key [+ value]) in one direction
+        if plan.name == "msd":
+            kv_arg = "true" if key_value else "false"
+            names = {"histogram": "histogram_msd_kernel<32u, %du, 2u>" % plan.bits,
+                     "spine": "spine_msd_kernel<%du>" % plan.bits,
+                     "scatter": "scatter_msd_kernel<%du, 32, %s>" % (plan.bits, kv_arg),
+                     "bucket": "bucket_sort2_kernel<%du, 36, %s, %s>" % (plan.bits, kv_arg, "false" if key_value else "true"),
+                     "fallback": "4 x " + kernel_name(version, "key-value" if key_value else "keys") + " (returning on the verdict)"}
+            bytes_of = {"histogram": 4.0 * n, "spine": 0.0, "scatter": 2 * item * n, "bucket": 2 * item * n, "fallback": 0.0}
+            what = {"histogram": "HBM read", "spine": "launch latency (4 MiB of 16-bit counts)",
+                    "scatter": "HBM read + write in runs of 128 bytes", "bucket": "LDS (two in-LDS passes per key between one read and one write)",
+                    "fallback": "launch latency"}
+        else:
+            names = {"histogram": "histogram_kernel<32u, false>", "sweep": kernel_name(version, "key-value" if key_value else "keys")}
+            bytes_of = {"histogram": 4.0 * n, "sweep": 2 * item * n}
+            what = {"histogram": "HBM read", "sweep": "HBM read + write (the tile's latency chain)"}
+        out = {}
+        for part, ms_stamped in stamped.items():
+            ms = max(ms_stamped - overhead_ms, 1e-6)
+            entry = {"kernel": names[part], "avg_launch_ms": ms, "stamped_launch_ms": ms_stamped,
+                     "algorithmic_bytes_per_launch": bytes_of[part], "limited_by": what[part]}
+            if bytes_of[part] > 0:
+                entry["achieved"] = bytes_of[part] / (ms * 1e-3) / 1e9
+                entry["frac"] = entry["achieved"] / HBM_PEAK_GBPS
+            traffic = ((pmc or {}).get("plan_kernels") or {}).get(("key_value:" if key_value else "keys:") + part)
+            if traffic:
+                entry["traffic"] = traffic
+                entry["traffic_GBps"] = traffic / (ms * 1e-3) / 1e9
+                entry["traffic_frac"] = entry["traffic_GBps"] / HBM_PEAK_GBPS
+            out[part] = entry
+        return plan, out
+
+    plan_keys, kernels_keys = kernels_of(stamped_keys, False)
+    plan_kv, kernels_kv = kernels_of(stamped_kv, True)
+
+    def dominant(kernels):
+        movers = {k: v for k, v in kernels.items() if v["algorithmic_bytes_per_launch"] > 0 and k != "histogram"}
+        return max(movers.items(), key=lambda kv: kv[1]["avg_launch_ms"])
+
+    dom_part, dom = dominant(kernels_keys)
+    dom_part_kv, dom_kv = dominant(kernels_kv)
+    roofline = {
+        "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s", "frac": dom["frac"], "traffic": dom.get("traffic"),
+        "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "avg_launch_ms": dom["avg_launch_ms"],
+        "stamped_launch_ms": dom["stamped_launch_ms"], "event_overhead_ms": overhead_ms,
+        "launch_time_source": source, "measured_on": box,
+        "note": ("the dominant kernel is the one with the longest launch among those that move the data; 'bound' "
+                 "prices it against HBM as the contract asks, 'limited_by' says what it actually waits for"),
+        "limited_by": dom["limited_by"], "plan": plan_keys.name, "plan_bits": int(plan_keys.bits),
+        "kernels": kernels_keys,
+        "whole_sort": {"algorithmic_bytes": float(plan_keys.bytesPerElement) * n,
+                       "bytes_per_item": int(plan_keys.bytesPerElement),
+                       "achieved": plan_keys.bytesPerElement * n / (med_keys_ms * 1e-3) / 1e9,
+                       "frac": plan_keys.bytesPerElement * n / (med_keys_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                       "four_pass_equivalent_frac": KEYS_BYTES_PER_ITEM * n / (med_keys_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+        "key_value": {"kernel": dom_kv["kernel"], "avg_launch_ms": dom_kv["avg_launch_ms"],
+                      "stamped_launch_ms": dom_kv["stamped_launch_ms"], "achieved": dom_kv["achieved"],
+                      "frac": dom_kv["frac"], "traffic": dom_kv.get("traffic"), "limited_by": dom_kv["limited_by"],
+                      "plan": plan_kv.name, "plan_bits": int(plan_kv.bits), "kernels": kernels_kv,
+                      "whole_sort_bytes_per_item": int(plan_kv.bytesPerElement),
+                      "whole_sort_achieved": plan_kv.bytesPerElement * n / (med_kv_ms * 1e-3) / 1e9,
+                      "whole_sort_frac": plan_kv.bytesPerElement * n / (med_kv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                      "four_pass_equivalent_frac": KV_BYTES_PER_ITEM * n / (med_kv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+    }
+    if "traffic" in dom:
+        roofline["traffic_GBps"], roofline["traffic_frac"] = dom["traffic_GBps"], dom["traffic_frac"]
+    ceiling = committed_ceiling()
+    if ceiling:
+        roofline["ceiling_frac"] = ceiling
     rocprof = committed_rocprof_averages(version)
     if rocprof:
-        roofline["rocprof"] = rocprof
-    # counter-measured HBM bytes of the same kernels (profiles/pmc_traffic.json, only while its stamp matches this
-    # library) over the launch duration measured above: the "measured HBM GB/s" beside the algorithmic figure
-    if pmc:
-        roofline["traffic_GBps"] = pmc["onesweep_keys_bytes_per_launch"] / (sweep_ms * 1e-3) / 1e9
-        roofline["traffic_frac"] = roofline["traffic_GBps"] / HBM_PEAK_GBPS
-        kv_bytes = pmc.get("onesweep_key_value_bytes_per_launch")
-        if kv_bytes:
-            roofline["key_value"]["traffic"] = kv_bytes
-            roofline["key_value"]["traffic_GBps"] = kv_bytes / (sweep_kv_ms * 1e-3) / 1e9
-            roofline["key_value"]["traffic_frac"] = roofline["key_value"]["traffic_GBps"] / HBM_PEAK_GBPS
+        roofline["rocprof"] = rocprof   # (carries the box it was taken on: "measured_on")
 
     result = {
         "metric": "GItems/s at N=2^25 (keys & key+value); achieved HBM GB/s vs peak",
@@ -419,14 +589,25 @@ def main():
                                f"(BASELINE.json configs[1]); key+value (configs[2]) under key_value",
                    "n": n, "arrays_per_step_per_gpu": 1,
                    "parallelism": "independent arrays, one per GPU, no data-path collective" if distributed else "single GPU",
-                   "tile": version, "ranks": [{"rank": r.rank, "status": r.status} for r in records]},
+                   "tile": version, "plan": plan_keys.name, "ranks": [{"rank": r.rank, "status": r.status} for r in records]},
         "median_gpu_ms_per_sort": med_keys_ms, "median_gitems_per_s": n / (med_keys_ms * 1e-3) / 1e9,
         "key_value": {"value": value_kv, "unit": "GItems/s", "ms_per_step": wall_kv / args.steps * 1e3,
                       "median_gpu_ms_per_sort": med_kv_ms, "median_gitems_per_s": n / (med_kv_ms * 1e-3) / 1e9},
         "targets": {"cub_onesweep_rtx5080_keys": 22.36, "cub_onesweep_rtx5080_key_value": 11.67,
                     "note": "north-star floor from the reference README (other hardware), not a vs_baseline"},
         "roofline": roofline,
+        "setup": {"input_generation_and_upload_s": setup_s, "streams": len(pristine[0]),
+                  "host_streams_in_flight": GENERATOR_THREADS},
     }
+    if extras and not args.no_sweep:
+        t_curve = time.perf_counter()
+        result["sweep"] = size_curve(torch, executor, sorter, fresh, device, list(range(18, args.log2n + 1)))
+        if args.log2n == 25:
+            result["hbm_resident"] = hbm_resident_point(torch, executor, sorter, fresh, device)
+        result["sweep_protocol"] = ("bench/bench.cc:15-20,66-112: 1 warm-up + 10 timed sorts of fresh std::mt19937 data per "
+                                    "size and mode, median, GPU time between two events around the sort; measured on " + box +
+                                    " in %.1f s" % (time.perf_counter() - t_curve))
+    del pristine, fresh
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(n)
     if rank == 0:

@@ -87,6 +87,26 @@ def check_against_oracle(torch, sorter, oracle, keys, values=None, **kw):
         assert np.array_equal(gv, ev)
 
 
+MSD_FROM = 16_252_929   # vrdx_api.cpp MsdBits: sorts of this many elements and more record the MSD plan in front of the passes
+
+
+def decline_msd(keys):
+    """Tests that are ABOUT the four passes (tile plans, block sums, the look-back) at sizes where uniform keys would take
+    the MSD plan recorded in front of them: 40000 keys spread over the array get the same top eleven bits -- a bucket
+    beyond the plan's capacity of 36864 whether it scatters by ten or eleven bits -- and the device turns the plan down.
+    The keys stay as good as uniform for everything else.  Returns keys (modified in place)."""
+    n = len(keys)
+    if n >= MSD_FROM:
+        step = max(1, n // 40000)
+        keys[::step][:40000] = (keys[::step][:40000] & np.uint32(0x001FFFFF)) | np.uint32(0x2AC << 21)
+    return keys
+
+
+def plan_word(storage):
+    """word 1 of the storage: 3 = a plan in front of the passes (nine-bit, MSD) took the sort"""
+    return int(storage[4:8].cpu().numpy().view(np.uint32)[0])
+
+
 SIZES = [0, 1, 2, 63, 64, 65, 511, 512, 513, 4095, 4096, 4097, 8191, 8192, 8193, 12411, 16383, 16384,
          16385, 24577, 65539, 262144, 262145, (1 << 20) + 7]
 
@@ -323,6 +343,27 @@ def test_timestamp_contract(torch_mod, sorter, oracle):
     pool.destroy()
 
 
+def test_timestamp_contract_of_the_msd_plan(torch_mod, sorter, oracle):
+    """The same 15 slots when the MSD plan takes the sort (include/vk_radix_sort.h): its three stages carry the names they
+    have in the reference -- slot 2 "upsweep" (the histogram with per-tile counts), 3 "spine" (a real stage here), 4
+    "downsweep" (the scatter) -- the bucket sorts are pass 1's "upsweep" (slot 5), and the four returning passes share the
+    slots behind.  Monotone, all recorded, the whole sort = slot 14 - slot 0."""
+    import vulkan_radix_sort_amd as vrdx
+    pool = vrdx.QueryPool(15)
+    n = MSD_FROM + 11
+    k, v = oracle.generate(1, n, 32)
+    kept = []
+    gk, gv = gpu_sort(torch_mod, sorter, k, v, query_pool=pool, storage_out=kept)
+    ek, ev, _ = oracle.sort(k, v)
+    assert np.array_equal(gk, ek) and np.array_equal(gv, ev) and plan_word(kept[0]) == 3
+    ts = pool.results_ns()
+    assert len(ts) == 15 and ts[0] == 0 and all(b >= a for a, b in zip(ts, ts[1:]))
+    assert ts[2] > ts[1] and ts[3] > ts[2] and ts[4] > ts[3] and ts[5] > ts[4]      # four real stages
+    assert ts[4] - ts[3] > 10 * (ts[3] - ts[2])                                       # ... of which the spine is the short one
+    assert ts[6] == ts[5] and ts[9] == ts[8] == ts[7] and ts[14] == ts[13] and ts[14] - ts[5] < ts[5] - ts[4]
+    pool.destroy()
+
+
 def test_sorts_on_a_side_stream_and_two_sorters_concurrently(torch_mod, oracle):
     # sorter is immutable: different streams + different storage may run concurrently
     # (SURVEY.md section 8b "Threading")
@@ -520,7 +561,11 @@ def test_tail_split_tiles_at_their_boundaries(torch_mod, sorter, oracle, n, key_
     rest behind the whole rounds; direct, and indirect with a device-side count that ends inside the FULL tiles (every
     tail tile and some full tiles start past the count) and one that ends inside the TAIL."""
     k, v = oracle.generate(13, n, 32)
+    decline_msd(k)   # (these sizes record the MSD plan in front of the passes: the tile plans under test are the fallback's)
     values = v if key_value else None
+    kept = []
+    gpu_sort(torch_mod, sorter, k, values, storage_out=kept)
+    assert plan_word(kept[0]) != 3
     check_against_oracle(torch_mod, sorter, oracle, k, values)
     whole = (n // ROUND) * ROUND if key_value else (n // (2 * ROUND)) * 2 * ROUND
     for count in (whole - 70001, whole + (n - whole) // 2 + 1):
@@ -561,6 +606,68 @@ def test_nine_bit_hybrid_plan_and_its_fallback_at_the_sub_bucket_capacity(torch_
         assert np.array_equal(gk, ek) and np.array_equal(gp, ep), heavy
 
 
+@pytest.mark.parametrize("n,key_value", [(MSD_FROM, False), (MSD_FROM, True), (20_000_003, True), (1 << 25, False),
+                                         (1 << 25, True), (36_500_000, False), (37_000_001, False), (45_000_000, True)])
+def test_msd_plan_and_its_fallback_at_the_bucket_capacity(torch_mod, sorter, oracle, n, key_value):
+    """Sorts of 16.25 M elements and more record the MSD plan in front of their four passes (vrdx_kernels.hip, "MSD plan"):
+    per-tile counts of the top ten or eleven bits, a spine, ONE stable scatter by those bits and one workgroup per bucket
+    that sorts it by the remaining bits in two in-LDS passes; the DEVICE keeps the four passes when a bucket exceeds the
+    capacity of 36864.  Uniform keys with ONE bucket brought to exactly 36864 elements (the plan applies: word 1 of the
+    storage says 3) and to 36865 (it does not), keys-only or key+value (values = iota: the permutation itself), direct
+    and indirect with a smaller device-side count; the first size of the plan, the headline size, the last ten-bit and
+    first eleven-bit sizes."""
+    info = sorter.describe_plan(n, key_value)
+    assert info.name == "msd" and info.bits == (10 if n <= 36_600_000 else 11), (info.name, info.bits)
+    bits, cap = int(info.bits), 36864
+    shift, low = np.uint32(32 - bits), np.uint32((1 << (32 - bits)) - 1)
+    bucket = 0x155
+    rng = np.random.default_rng(n)
+    iota = np.arange(n, dtype=np.uint32)
+    for heavy in (cap, cap + 1):
+        k = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+        mine = (k >> shift) == bucket                               # nobody is in that bucket ...
+        elsewhere = rng.integers(0, bucket, size=int(mine.sum()), dtype=np.uint64).astype(np.uint32)
+        k[mine] = (k[mine] & low) | (elsewhere << shift)
+        where = rng.choice(n, size=heavy, replace=False)
+        k[where] = (k[where] & low) | np.uint32(bucket << int(shift))   # ... except exactly `heavy` keys
+        assert int(((k >> shift) == bucket).sum()) == heavy
+        values = iota if key_value else None
+        ek, ep, _ = oracle.sort(k, values)
+        kept = []
+        gk, gp = gpu_sort(torch_mod, sorter, k, values, storage_out=kept)
+        assert np.array_equal(gk, ek) and (not key_value or np.array_equal(gp, ep)), heavy
+        assert (plan_word(kept[0]) == 3) == (heavy == cap), (heavy, plan_word(kept[0]))
+        count = n - n // 3
+        ek, ep, _ = oracle.sort(k, values, count=count)
+        gk, gp = gpu_sort(torch_mod, sorter, k, values, count=count, indirect=True, max_count=n)
+        assert np.array_equal(gk, ek) and (not key_value or np.array_equal(gp, ep)), heavy
+
+
+@pytest.mark.parametrize("n", [MSD_FROM + 7, (1 << 25) - 12345])
+def test_msd_plan_stability_and_inputs_it_declines(torch_mod, sorter, oracle, n):
+    """The MSD plan on duplicate-heavy keys that fit its buckets (keys = eleven top bits | one middle bit | three low bits:
+    the stability of the scatter and of both bucket passes is what keeps equal keys' values in input order) and the
+    inputs it must turn down on the device: 24-bit keys, descending and ascending keys, four distinct values, all-equal."""
+    rng = np.random.default_rng(n)
+    iota = np.arange(n, dtype=np.uint32)
+    r = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+    dup = (r & np.uint32(0xFFE00000)) | (r & np.uint32(7)) | (((r >> np.uint32(3)) & np.uint32(1)) << np.uint32(12))
+    kept = []
+    gk, gp = gpu_sort(torch_mod, sorter, dup, iota, storage_out=kept)
+    ek, ep, _ = oracle.sort(dup, iota)
+    assert np.array_equal(gk, ek) and np.array_equal(gp, ep) and plan_word(kept[0]) == 3
+    four = np.array([0xFFFFFFFF, 0, 0x80000001, 0x7FFFFF00], np.uint32)[rng.integers(0, 4, n)]
+    for name, k in (("24-bit", r >> np.uint32(8)), ("descending", (n - 1 - iota).astype(np.uint32)), ("ascending", iota.copy()),
+                    ("four values", four), ("all equal", np.full(n, 0x12345678, np.uint32))):
+        kept = []
+        gk, gp = gpu_sort(torch_mod, sorter, k, iota, storage_out=kept)
+        ek, ep, _ = oracle.sort(k, iota)
+        assert np.array_equal(gk, ek) and np.array_equal(gp, ep), name
+        assert plan_word(kept[0]) != 3, name
+        gk, _ = gpu_sort(torch_mod, sorter, k)
+        assert np.array_equal(gk, ek), name
+
+
 @pytest.mark.parametrize("n", [ROUND, ROUND + 4097, ROUND + ROUND // 4 + 3, 2 * ROUND - 5, 2 * ROUND])
 def test_block_sums_in_sorts_of_one_round(torch_mod, sorter, oracle, n):
     """Sorts of ONE round of 64 ... 256 tiles of 32768 keys and more on the four-pass plan take their prefixes from block
@@ -570,7 +677,8 @@ def test_block_sums_in_sorts_of_one_round(torch_mod, sorter, oracle, n):
     k, _ = oracle.generate(17, n, 32)
     # (uniform keys of these sizes would take the nine-bit hybrid plan recorded in front of the passes: one nine-bit value
     # occurring 40000 times sends the sort down its four passes, which is where the block sums are)
-    k[:: max(1, n // 40000)][:40000] = (k[:: max(1, n // 40000)][:40000] & np.uint32(0x007FFFFF)) | np.uint32(0x0AB << 23)
+    # (the same top ELEVEN bits: the sizes from 16.25 M up record the MSD plan instead, whose buckets are ten bits wide)
+    k[:: max(1, n // 40000)][:40000] = (k[:: max(1, n // 40000)][:40000] & np.uint32(0x001FFFFF)) | np.uint32(0x0AB << 23)
     iota = np.arange(n, dtype=np.uint32)
     kept = []
     ek, _, _ = oracle.sort(k)

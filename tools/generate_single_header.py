@@ -50,6 +50,13 @@ def expected_kernels():
                 for even in ((0, 1) if kpt == 32 else (0,)):
                     names.append("_ZN4vrdx15onesweep_kernelILi%dELi%dELb%dELb%dELb%dEEEvNS_12OnesweepArgsE"
                                  % (threads, kpt, kv, atomic, even))
+    # the MSD plan: histogram with per-tile counts, spine, scatter, two-pass bucket sort; the packed-counter order check
+    names.append("_ZN4vrdx29lds_order_check_packed_kernelEPjS0_")
+    for bits in (10, 11):
+        names.append("_ZN4vrdx16spine_msd_kernelILj%dEEEvNS_7MsdArgsE" % bits)
+        names += ["_ZN4vrdx20histogram_msd_kernelILj%dELj%dELj2EEEvPKjjS2_PjS3_PDv4_jjS3_j" % (c, bits) for c in (8, 32)]
+        names += ["_ZN4vrdx18scatter_msd_kernelILj%dELb%dEEEvNS_7MsdArgsE" % (bits, kv) for kv in (0, 1)]
+        names += ["_ZN4vrdx19bucket_sort2_kernelILj%dELi36ELb%dEEEvNS_7MsdArgsE" % (bits, kv) for kv in (0, 1)]
     for kv in (0, 1):  # 32768-element buckets: one-atomic ranking only
         names.append("_ZN4vrdx18bucket_sort_kernelILi1024ELi32ELb%dELb1ELi256EEEvNS_14BucketSortArgsE" % kv)
     for kpt in (4, 8, 16):

@@ -26,6 +26,7 @@ if "--json" in sys.argv:
     out = sys.argv[sys.argv.index("--json") + 1]
     with open(out, "w") as f:
         json.dump({"file": os.path.basename(sys.argv[1]), "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py",
+                   "measured_on": os.uname().nodename,
                    "kernel_source_sha256": bench.kernel_source_digest(), "library": vrdx.version_string(),
                    "kernels": rows}, f, indent=1)
         f.write("\n")

@@ -61,7 +61,8 @@ def main():
     f16 = known / pick(fetch, "copy_uint4")     # 16 B/lane reads
     w4 = known / pick(write, "copy_dword")
     w16 = known / pick(write, "copy_uint4")
-    out = {"n": n, "library": library_version(), "kernel_source_sha256": kernel_source_digest(), "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; counter units "
+    out = {"n": n, "library": library_version(), "kernel_source_sha256": kernel_source_digest(),
+           "measured_on": os.uname().nodename, "plan_kernels": {}, "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; counter units "
                              "calibrated on copy kernels of known size in the same run (4 B/lane and 16 B/lane)",
            "bytes_per_fetch_unit": {"dword": f4, "uint4": f16}, "bytes_per_write_unit": {"dword": w4, "uint4": w16},
            "kernels": {}}
@@ -71,9 +72,20 @@ def main():
             # onesweep_kernel<THREADS, KPT, KV, ATOMIC_RANK, DYN>: third argument; onesweep_pair_kernel<THREADS, KPT, DYN> is keys-only
             targs = [t.strip() for t in name.split("<", 1)[1].split(">", 1)[0].split(",")]
             kind = "key_value" if "pair" not in name and len(targs) > 2 and targs[2] == "true" else "keys"
+        elif "scatter_msd" in name or "bucket_sort2" in name:
+            # the MSD plan's kernels: 4-byte loads; the scatter stores quads (16 B), the bucket kernel words
+            targs = [t.strip() for t in name.split("<", 1)[1].split(">", 1)[0].split(",")]
+            mode = "key_value" if targs[2] == "true" else "keys"
+            part = "scatter" if "scatter_msd" in name else "bucket"
+            rd = fetch[name] * f4
+            wr = write.get(name, 0.0) * (w16 if part == "scatter" else w4)
+            kind = "msd_%s_%s" % (part, mode)
+            out["plan_kernels"]["%s:%s" % (mode, part)] = rd + wr
         elif "histogram" in name:
             rd, wr = fetch[name] * f16, write.get(name, 0.0) * w4
             kind = "histogram"
+            if "histogram_msd" in name:
+                out["plan_kernels"]["keys:histogram"] = out["plan_kernels"]["key_value:histogram"] = rd + wr
         else:
             continue
         out["kernels"][name] = {"kind": kind, "launches": calls[name], "hbm_read_bytes_per_launch": rd,

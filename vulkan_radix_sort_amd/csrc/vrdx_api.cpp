@@ -229,11 +229,7 @@ uint32_t Hybrid9Capacity(bool atomicRank, uint32_t elementCount, uint32_t hybrid
 // at these sizes): ten bits up to 36.6 M keys / 32.5 M pairs, eleven bits up to twice that.  Returns the bits or 0.
 // One-atomic ranking only.  VRDX_MSD=0 switches it off (VRDX_HYBRID=0 and a forced tile geometry as well); VRDX_MSD_FROM=n
 // records it from n elements up instead (measurements: below its default range it replaces the other two plans).
-uint32_t MsdTileKeys(uint32_t elementCount) {
-  static const int knob = TuningKnob("VRDX_MSD_TILE");  // measurements: 16384 | 32768
-  const uint32_t wanted = knob == 16384 ? 16384u : vrdx::kMsdTileKeys;
-  return vrdx::RoundUp(elementCount, wanted) <= vrdx::kMsdMaxTiles ? wanted : vrdx::kMsdTileKeys;
-}
+uint32_t MsdTileKeys(uint32_t) { return vrdx::kMsdTileKeys; }
 
 uint32_t MsdBits(bool atomicRank, bool keyValue, uint32_t elementCount, uint32_t* capacity) {
   static const bool enabled = [] {

@@ -52,6 +52,18 @@ namespace vrdx {
 #ifndef VRDX_NT_LAST_PASS
 #define VRDX_NT_LAST_PASS 0
 #endif
+// Measurement switches of the MSD plan's kernels (tools/r05/ablate.sh builds the variants): VRDX_MSD_XCD = 0: tiles handed
+// out round-robin instead of in consecutive chunks per XCD; VRDX_MSD_NT_LOADS / VRDX_MSD_BUCKET_NT: non-temporal loads in
+// the scatter / the bucket kernel.
+#ifndef VRDX_MSD_XCD
+#define VRDX_MSD_XCD 1
+#endif
+#ifndef VRDX_MSD_NT_LOADS
+#define VRDX_MSD_NT_LOADS 1
+#endif
+#ifndef VRDX_MSD_BUCKET_NT
+#define VRDX_MSD_BUCKET_NT 0
+#endif
 
 
 // Timing-only phase trace for tools/trace.sh (never defined in the product build): thread 0 of
@@ -2363,18 +2375,31 @@ __global__ __launch_bounds__(1024) void spine_msd_kernel(MsdArgs a) {
 // and 64 KiB of counters would not fit side by side -- and out in quads like the pass kernels, boundary quads by the thread
 // that owns the run (two runs per thread here).  The tile's 2^BITS bases arrive with the keys: one row of prefixes and the
 // bucket bases, loaded first.
-template <uint32_t BITS, int KPT>
+//
+// XCD-AWARE tile order.  A tile's run of bucket d is followed in memory by the NEXT tile's run of bucket d, and with runs of
+// 128 bytes (32768 keys over 1024 buckets) nearly every 128-byte line is written by two tiles.  The eight XCDs have an L2
+// each: written from two of them, a line leaves both as a partial line.  Measured at 2^25 keys (tools/r05/ablate.sh,
+// profiles/r05_msd_scatter.txt): no stores 48.6 us, contiguous stores 64.0, the real runs 98.6-106.9 with tiles handed out
+// round-robin -- and 91.3 with this order: XCD x (the workgroups b with b % 8 == x: observed dispatch order, for speed only,
+// nothing depends on it) takes the CONSECUTIVE tiles [x C, (x + 1) C), C = ceil(tiles / 8), so that the lines of a
+// bucket's range are completed inside one L2.  The grid is 8 C workgroups; one without a tile returns at once.
+// NON-TEMPORAL loads of the keys and values (read once): they then do not push the lines the scatter is still completing
+// out of that L2, nor the scattered data out of the caches before the bucket kernel reads them: 79.4 instead of 91.3 us,
+// and the bucket kernel behind it 112 instead of 116.
+// (A persistent form -- one workgroup per CU striding through the tiles, the next tile's keys prefetched into the registers
+// the staged keys had left, every store a counted buffer store so that the prefetch could be waited for without draining the
+// scatter -- was built and measured: 91.3 against 86.0 us for one tile per workgroup.  Tiles of 16384 keys, two workgroups
+// per CU: 97.6 against 93.3.  Neither kept.)
+template <uint32_t BITS>
 constexpr size_t ScatterMsdLdsWords() {
-  return (size_t)1024 * KPT + (1u << BITS) + 32;
+  return (size_t)kMsdTileKeys + (1u << BITS) + 32;
 }
 
-// KPT = 32: tiles of 32768 keys, one workgroup per CU (132-136 KiB of LDS); KPT = 16: 16384 keys, 68-72 KiB, two workgroups per
-// CU -- two independent tile lives per CU, which nothing in this kernel makes expensive (there is no per-tile chain).
-template <uint32_t BITS, int KPT, bool KV>
-__global__ __launch_bounds__(1024, (KPT <= 16 ? 8 : 4)) void scatter_msd_kernel(MsdArgs a) {
-  constexpr int THREADS = 1024, WAVES = THREADS / 64;
-  constexpr uint32_t TILE = THREADS * KPT, D = 1u << BITS, SHIFT = 32u - BITS, MASK = D - 1u, ROW = D / 2u;
-  static_assert(ROW <= (uint32_t)THREADS && WAVES * ROW <= TILE && KPT % 8 == 0, "geometry");
+template <uint32_t BITS, bool KV>
+__global__ __launch_bounds__(1024) void scatter_msd_kernel(MsdArgs a) {
+  constexpr int THREADS = 1024, KPT = 32, WAVES = THREADS / 64;
+  constexpr uint32_t TILE = kMsdTileKeys, D = 1u << BITS, SHIFT = 32u - BITS, MASK = D - 1u, ROW = D / 2u;
+  static_assert(THREADS * KPT == TILE && ROW <= (uint32_t)THREADS && WAVES * ROW <= TILE, "geometry");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* const sorted = smem;               // TILE: keys (then values) regrouped by digit
   uint32_t* const counters = smem;             // WAVES x ROW packed counters; dead before the first key is staged
@@ -2385,22 +2410,24 @@ __global__ __launch_bounds__(1024, (KPT <= 16 ? 8 : 4)) void scatter_msd_kernel(
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
-  const uint32_t tile = blockIdx.x;
+  // the grid is 8 C workgroups, C = ceil(tiles / 8): workgroup b takes tile (b % 8) C + b / 8 of its XCD's chunk
+  const uint32_t perXcd = gridDim.x / 8u;
+  const uint32_t tile = VRDX_MSD_XCD ? (blockIdx.x % 8u) * perXcd + blockIdx.x / 8u : blockIdx.x;
   const uint32_t tileStart = tile * TILE;
   // (loads first, verdict second: the keys fly while the overflow word arrives)
-  const uint32_t valid = tileStart < n ? ((n - tileStart) < TILE ? (n - tileStart) : TILE) : 0u;
+  const uint32_t valid = tile < a.tiles && tileStart < n ? ((n - tileStart) < TILE ? (n - tileStart) : TILE) : 0u;
   const uint32_t tileEnd = tileStart + valid;
   const uint32_t loadBase = tileStart + wave * (KPT * 64) + lane;
   uint32_t key[KPT];
-  LoadStriped<KPT>(a.keysCaller, loadBase, tileEnd, valid == TILE, 0xFFFFFFFFu, key);  // pad: downsweep.slang:81
+  LoadStriped<KPT, VRDX_MSD_NT_LOADS != 0>(a.keysCaller, loadBase, tileEnd, valid == TILE, 0xFFFFFFFFu, key);  // pad: downsweep.slang:81
   uint32_t prefixWord = 0, base0 = 0, base1 = 0;
-  if ((uint32_t)tid < ROW) {
+  if ((uint32_t)tid < ROW && valid != 0) {
     prefixWord = a.tileCounts[(size_t)tile * ROW + tid];
     base0 = a.bucketBase[2 * tid];
     base1 = a.bucketBase[2 * tid + 1];
   }
   if (*a.overflowWord != 0u) return;  // a bucket beyond the capacity: the four passes behind this launch run
-  if (tile == 0 && tid == 0) *a.planWord = 3u;  // for the launches behind this one
+  if (blockIdx.x == 0 && tid == 0) *a.planWord = 3u;  // for the launches behind this one
   if (valid == 0) return;
 
   uint32_t* const myRow = counters + wave * ROW;
@@ -2429,7 +2456,7 @@ __global__ __launch_bounds__(1024, (KPT <= 16 ? 8 : 4)) void scatter_msd_kernel(
   LdsBarrier();
   // key+value: the values are fetched now and land while the keys are scattered (like scatter9_kernel)
   uint32_t val[KV ? KPT : 1];
-  if constexpr (KV) LoadStriped<KPT>(a.valuesCaller, loadBase, tileEnd, valid == TILE, 0u, val);  // pad: downsweep.slang:85
+  if constexpr (KV) LoadStriped<KPT, VRDX_MSD_NT_LOADS != 0>(a.valuesCaller, loadBase, tileEnd, valid == TILE, 0u, val);  // pad: downsweep.slang:85
 
   // scatter: whole single-digit quads in the main loop, the quads around a run's start by the thread that owns the run
   constexpr int QUADS = KPT / 4;
@@ -2546,8 +2573,8 @@ __global__ __launch_bounds__(1024) void bucket_sort2_kernel(MsdArgs a) {
   }
   uint32_t key[KPT];
   uint32_t val[KV ? KPT : 1];
-  LoadStriped<KPT, false, DYN>(keysIn, first, n, false, 0xFFFFFFFFu, key, slots);
-  if constexpr (KV) LoadStriped<KPT, false, DYN>(valuesIn, first, n, false, 0u, val, slots);
+  LoadStriped<KPT, VRDX_MSD_BUCKET_NT != 0, DYN>(keysIn, first, n, false, 0xFFFFFFFFu, key, slots);
+  if constexpr (KV) LoadStriped<KPT, VRDX_MSD_BUCKET_NT != 0, DYN>(valuesIn, first, n, false, 0u, val, slots);
 
   uint32_t* const myRow = counters + wave * ROW;
 #pragma unroll 1
@@ -2558,6 +2585,7 @@ __global__ __launch_bounds__(1024) void bucket_sort2_kernel(MsdArgs a) {
     for (uint32_t i = 0; i < ROW / 256u; ++i) reinterpret_cast<u32x4*>(myRow)[lane + 64 * i] = u32x4{0u, 0u, 0u, 0u};
     uint32_t rank[KPT / 2];
     RankPacked16<KPT, DYN>(key, shift, mask, myRow, lane, rank, slots);
+    ForgetDerivedValues<KPT>(key);
     LdsBarrier();
     uint32_t firstNow = first;  // (see SortInWorkgroup: keeps the read-back addresses out of registers across the passes)
     asm volatile("" : "+v"(firstNow));
@@ -3049,12 +3077,8 @@ static hipError_t PrepareMsdBits() {
   } kernels[] = {
       {reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, BITS, 2>), HistMsdLdsBytes(kHistCopies)},
       {reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, BITS, 2>), HistMsdLdsBytes(kHistCopiesLarge)},
-      {reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, BITS, 1>), HistMsdLdsBytes(kHistCopies)},
-      {reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, BITS, 1>), HistMsdLdsBytes(kHistCopiesLarge)},
-      {reinterpret_cast<const void*>(&scatter_msd_kernel<BITS, 32, false>), ScatterMsdLdsWords<BITS, 32>() * 4},
-      {reinterpret_cast<const void*>(&scatter_msd_kernel<BITS, 32, true>), ScatterMsdLdsWords<BITS, 32>() * 4},
-      {reinterpret_cast<const void*>(&scatter_msd_kernel<BITS, 16, false>), ScatterMsdLdsWords<BITS, 16>() * 4},
-      {reinterpret_cast<const void*>(&scatter_msd_kernel<BITS, 16, true>), ScatterMsdLdsWords<BITS, 16>() * 4},
+      {reinterpret_cast<const void*>(&scatter_msd_kernel<BITS, false>), ScatterMsdLdsWords<BITS>() * 4},
+      {reinterpret_cast<const void*>(&scatter_msd_kernel<BITS, true>), ScatterMsdLdsWords<BITS>() * 4},
       {reinterpret_cast<const void*>(&bucket_sort2_kernel<BITS, kMsdCapKeys / 1024, false>), BucketSort2LdsWords<kMsdCapKeys / 1024>() * 4},
       {reinterpret_cast<const void*>(&bucket_sort2_kernel<BITS, kMsdCapKeyValue / 1024, true>), BucketSort2LdsWords<kMsdCapKeyValue / 1024>() * 4},
   };
@@ -3081,18 +3105,15 @@ hipError_t LaunchHistogramMsd(hipStream_t stream, uint32_t grid, const uint32_t*
   const uint32_t vecs = statusClearBytes / 16u;
   const bool many = maxCount >= kHistManyCopiesFrom;
   const void* kernel;
-  if (tileKeys != 16384u && tileKeys != 32768u) return hipErrorInvalidValue;
-  const bool two = tileKeys == 32768u;
+  // (tiles of 16384 keys -- two scatter workgroups per CU, the GROUPS = 1 form of the histogram -- were built and measured
+  // in round 5: scatter 97.6 instead of 93.3 us keys-only at 2^25, histogram 41 instead of 37; not instantiated)
+  if (tileKeys != kMsdTileKeys) return hipErrorInvalidValue;
   if (bits == 10)
-    kernel = many ? (two ? reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, 10, 2>)
-                         : reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, 10, 1>))
-                  : (two ? reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, 10, 2>)
-                         : reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, 10, 1>));
+    kernel = many ? reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, 10, 2>)
+                  : reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, 10, 2>);
   else if (bits == 11)
-    kernel = many ? (two ? reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, 11, 2>)
-                         : reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, 11, 1>))
-                  : (two ? reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, 11, 2>)
-                         : reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, 11, 1>));
+    kernel = many ? reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, 11, 2>)
+                  : reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, 11, 2>);
   else
     return hipErrorInvalidValue;
   return Launch(kernel, grid, kHistThreads, HistMsdLdsBytes(many ? kHistCopiesLarge : kHistCopies), stream, keys, maxCount,
@@ -3106,23 +3127,23 @@ hipError_t LaunchSpineMsd(hipStream_t stream, const MsdArgs& args) {
   return hipErrorInvalidValue;
 }
 
-template <uint32_t BITS>
-static hipError_t LaunchScatterMsdBits(hipStream_t stream, bool keyValue, const MsdArgs& args) {
-  if (args.tileKeys == 32768u)
-    return Launch(keyValue ? reinterpret_cast<const void*>(&scatter_msd_kernel<BITS, 32, true>)
-                           : reinterpret_cast<const void*>(&scatter_msd_kernel<BITS, 32, false>),
-                  args.tiles, 1024, ScatterMsdLdsWords<BITS, 32>() * 4, stream, args);
-  if (args.tileKeys == 16384u)
-    return Launch(keyValue ? reinterpret_cast<const void*>(&scatter_msd_kernel<BITS, 16, true>)
-                           : reinterpret_cast<const void*>(&scatter_msd_kernel<BITS, 16, false>),
-                  args.tiles, 1024, ScatterMsdLdsWords<BITS, 16>() * 4, stream, args);
-  return hipErrorInvalidValue;
-}
-
 hipError_t LaunchScatterMsd(hipStream_t stream, bool keyValue, const MsdArgs& args) {
-  if (args.bits == 10) return LaunchScatterMsdBits<10>(stream, keyValue, args);
-  if (args.bits == 11) return LaunchScatterMsdBits<11>(stream, keyValue, args);
-  return hipErrorInvalidValue;
+  const void* kernel;
+  size_t lds;
+  if (args.tileKeys != kMsdTileKeys) return hipErrorInvalidValue;
+  if (args.bits == 10) {
+    kernel = keyValue ? reinterpret_cast<const void*>(&scatter_msd_kernel<10, true>)
+                      : reinterpret_cast<const void*>(&scatter_msd_kernel<10, false>);
+    lds = ScatterMsdLdsWords<10>() * 4;
+  } else if (args.bits == 11) {
+    kernel = keyValue ? reinterpret_cast<const void*>(&scatter_msd_kernel<11, true>)
+                      : reinterpret_cast<const void*>(&scatter_msd_kernel<11, false>);
+    lds = ScatterMsdLdsWords<11>() * 4;
+  } else {
+    return hipErrorInvalidValue;
+  }
+  // a multiple of 8 workgroups: eight chunks of consecutive tiles, one per XCD (see the kernel)
+  return Launch(kernel, 8u * ((args.tiles + 7u) / 8u), 1024, lds, stream, args);
 }
 
 hipError_t LaunchBucketSort2(hipStream_t stream, bool keyValue, const MsdArgs& args) {
