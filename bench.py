@@ -81,7 +81,7 @@ def random_u32(torch, n, seed, device):
     return to_device(torch, reference_stream(seed, n)[0], device)
 
 
-GENERATOR_THREADS = 4   # streams in flight on the host at a time: 4 x 256 MiB at N = 2^25
+GENERATOR_THREADS = 2   # streams in flight on the host at a time: 2 x 256 MiB at N = 2^25 (peak RSS 2.0 GiB, of which the runtime is most)
 
 
 def upload_streams(torch, n, seeds, device):
@@ -429,6 +429,7 @@ def spawn_ranks(args):
 
 
 def main():
+    t_process = time.perf_counter()
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
@@ -472,6 +473,7 @@ def main():
     t_setup = time.perf_counter()
     pristine = upload_streams(torch, n, list(range(seed0, seed0 + total + (CURVE_STREAMS if extras else 2))), device)
     setup_s = time.perf_counter() - t_setup
+    to_first_region_s = time.perf_counter() - t_process   # start of main() -> inputs resident, first barrier next
     fresh = (pristine[0][total:], pristine[1][total:])   # never sorted in place
     wall_keys, steps_keys = timed_sorts(torch, dist, executor, pristine, n, args.steps, args.warmup, False, device, distributed)
     wall_kv, steps_kv = timed_sorts(torch, dist, executor, pristine, n, args.steps, args.warmup, True, device, distributed)
@@ -596,8 +598,8 @@ def main():
         "targets": {"cub_onesweep_rtx5080_keys": 22.36, "cub_onesweep_rtx5080_key_value": 11.67,
                     "note": "north-star floor from the reference README (other hardware), not a vs_baseline"},
         "roofline": roofline,
-        "setup": {"input_generation_and_upload_s": setup_s, "streams": len(pristine[0]),
-                  "host_streams_in_flight": GENERATOR_THREADS},
+        "setup": {"input_generation_and_upload_s": setup_s, "seconds_to_first_timed_region": to_first_region_s,
+                  "streams": len(pristine[0]), "host_streams_in_flight": GENERATOR_THREADS},
     }
     if extras and not args.no_sweep:
         t_curve = time.perf_counter()
@@ -610,6 +612,8 @@ def main():
     del pristine, fresh
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(n)
+    import resource
+    result["setup"]["peak_rss_mib"] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0   # (Linux: KiB)
     if rank == 0:
         print(json.dumps(result))
     executor.close()

@@ -409,7 +409,7 @@ uint64_t Median(std::vector<uint64_t> v) {
 
 void Bench(Harness& h, const std::vector<int>& logs) {
   std::printf("%-10s %-6s %10s %10s %12s %10s %8s   [with 15 timestamps] stage ms (hist | scatter x4)\n", "n", "sort",
-              "gpu_ms", "wall_ms", "GItems/s", "GB/s", "%8TB/s");
+              "gpu_ms", "wall_ms", "GItems/s", "planGB/s", "%8TB/s");
   for (int lg : logs) {
     const uint32_t n = lg > 64 ? (uint32_t)lg : 1u << lg;  // an argument above 64 is the element count itself
     for (int kv = 0; kv < 2; ++kv) {
@@ -421,6 +421,9 @@ void Bench(Harness& h, const std::vector<int>& logs) {
       const uint32_t inout = Align16(n * 4u);
       h.reserve((size_t)2 * inout + 16, (size_t)req.size + StorageOffset());
       std::vector<uint64_t> gpu, wall, stage[5];
+      VrdxHipPlanInfo plan;
+      vrdxHipDescribePlan(h.sorter, n, kv, &plan);
+      const bool msd = plan.plan == VRDX_HIP_PLAN_MSD;
       for (int runIdx = 0; runIdx < 11; ++runIdx) {  // 1 warm-up + 10 timed, fresh data each run
         std::vector<uint32_t> v;
         auto k = Mt(n, runIdx + 1, 32, &v);
@@ -441,7 +444,14 @@ void Bench(Harness& h, const std::vector<int>& logs) {
         gpu.push_back(ts[14]);
         wall.push_back((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count());
         stage[0].push_back(ts[2] - ts[1]);
-        for (int p = 0; p < 4; ++p) stage[1 + p].push_back(ts[4 + 3 * p] - ts[3 + 3 * p]);
+        if (msd) {  // the MSD plan's slots (include/vk_radix_sort.h): spine | scatter | buckets | the four returning passes
+          stage[1].push_back(ts[3] - ts[2]);
+          stage[2].push_back(ts[4] - ts[3]);
+          stage[3].push_back(ts[5] - ts[4]);
+          stage[4].push_back(ts[14] - ts[5]);
+        } else {
+          for (int p = 0; p < 4; ++p) stage[1 + p].push_back(ts[4 + 3 * p] - ts[3 + 3 * p]);
+        }
       }
       // the same sort recorded WITHOUT a query pool (no per-stage events), bracketed by two events
       std::vector<uint64_t> bare;
@@ -473,12 +483,12 @@ void Bench(Harness& h, const std::vector<int>& logs) {
       }
       const double ms = Median(bare) / 1e6;       // headline: no per-stage events inside the sort
       const double msStamped = Median(gpu) / 1e6; // with the 15-slot timestamp contract active
-      const double bytes = (kv ? 68.0 : 36.0) * n;  // algorithmic bytes, SURVEY.md section 8(d)
+      const double bytes = (double)plan.bytesPerElement * n;  // the HBM bytes of the plan recorded for this size (vrdxHipDescribePlan; four passes: SURVEY.md section 8(d))
       const double gbps = bytes / (ms * 1e-3) / 1e9;
-      std::printf("%-10u %-6s %10.4f %10.4f %12.3f %10.1f %7.1f%%   [stamped %.4f] %.4f | %.4f %.4f %.4f %.4f\n", n,
+      std::printf("%-10u %-6s %10.4f %10.4f %12.3f %10.1f %7.1f%%   [stamped %.4f] %.4f %s %.4f %.4f %.4f %.4f\n", n,
                   kv ? "kv" : "keys", ms, Median(wall) / 1e6, n / (ms * 1e-3) / 1e9, gbps, 100.0 * gbps / 8000.0, msStamped,
-                  Median(stage[0]) / 1e6, Median(stage[1]) / 1e6, Median(stage[2]) / 1e6, Median(stage[3]) / 1e6,
-                  Median(stage[4]) / 1e6);
+                  Median(stage[0]) / 1e6, msd ? "| msd: spine scatter buckets fallback" : "|", Median(stage[1]) / 1e6,
+                  Median(stage[2]) / 1e6, Median(stage[3]) / 1e6, Median(stage[4]) / 1e6);
       std::fflush(stdout);
     }
   }

@@ -389,23 +389,6 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     layout = vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, tilePlan.tiles,
                               (uint64_t)reinterpret_cast<uintptr_t>(storage), blockSums, 0);
   }
-  if (!vrdx::LayoutFits(layout, elementCount)) {
-    // EVERY sort is checked, not only those with a plan in front: the layout depends on the tile plan, and the
-    // measurement knobs (VRDX_TAIL_SPLIT, VRDX_EVEN_SPLIT, VRDX_TILE_CONFIG) can select plans the offline sweep of
-    // tests/native/layout_check.cpp never saw.  Tiles of the kernel's full capacity without block rows fit for every N
-    // (2 (tiles - 1) KiB <= (P - 1) KiB from 8192 keys per tile up); smaller tiles cannot be helped: the scratch arrays
-    // must not leave the caller's allocation, so that sort is refused and says so (VRDX_HIP_STATUS_ENQUEUE_REFUSED).
-    tilePlan = vrdx::PlanTiles(elementCount, (uint32_t)sorter->computeUnits, (uint32_t)vrdx::kTileConfigs[configIndex].threads,
-                               (uint32_t)vrdx::kTileConfigs[configIndex].keysPerThread,
-                               (uint32_t)vrdx::kTileConfigs[configIndex].subTiles, false, false, 0);
-    blockSums = false;
-    layout = vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, tilePlan.tiles,
-                              (uint64_t)reinterpret_cast<uintptr_t>(storage), false, 0);
-    if (!vrdx::LayoutFits(layout, elementCount)) {
-      EnqueueCheck(sorter, "storage layout (status rows do not fit the reference's partition-histogram area)", hipErrorInvalidValue);
-      return;
-    }
-  }
   uint32_t* const keys = reinterpret_cast<uint32_t*>(BufferAddress(keysBuffer, keysOffset));
   uint32_t* const values =
       keyValue ? reinterpret_cast<uint32_t*>(BufferAddress(valuesBuffer, valuesOffset)) : nullptr;
@@ -435,6 +418,24 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     return;
   }
 
+  // (behind the empty sort and the one-workgroup sort above: neither touches the scratch arrays)
+  if (!vrdx::LayoutFits(layout, elementCount)) {
+    // EVERY sort of the general path is checked, not only those with a plan in front: the layout depends on the tile plan, and the
+    // measurement knobs (VRDX_TAIL_SPLIT, VRDX_EVEN_SPLIT, VRDX_TILE_CONFIG) can select plans the offline sweep of
+    // tests/native/layout_check.cpp never saw.  Tiles of the kernel's full capacity without block rows fit for every N
+    // (2 (tiles - 1) KiB <= (P - 1) KiB from 8192 keys per tile up); smaller tiles cannot be helped: the scratch arrays
+    // must not leave the caller's allocation, so that sort is refused and says so (VRDX_HIP_STATUS_ENQUEUE_REFUSED).
+    tilePlan = vrdx::PlanTiles(elementCount, (uint32_t)sorter->computeUnits, (uint32_t)vrdx::kTileConfigs[configIndex].threads,
+                               (uint32_t)vrdx::kTileConfigs[configIndex].keysPerThread,
+                               (uint32_t)vrdx::kTileConfigs[configIndex].subTiles, false, false, 0);
+    blockSums = false;
+    layout = vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, tilePlan.tiles,
+                              (uint64_t)reinterpret_cast<uintptr_t>(storage), false, 0);
+    if (!vrdx::LayoutFits(layout, elementCount)) {
+      EnqueueCheck(sorter, "storage layout (status rows do not fit the reference's partition-histogram area)", hipErrorInvalidValue);
+      return;
+    }
+  }
   // Clear count / plan / failure word and the 4x256 global histogram (reference :382) in one fill of 4112 bytes; status
   // region 0 is zeroed by the histogram kernel behind it.  Indirect: also copy the device-side count to where the reference keeps
   // it (:368-379); the kernels themselves read it straight from the caller's buffer.  (Direct: the

@@ -52,6 +52,13 @@ namespace vrdx {
 #ifndef VRDX_NT_LAST_PASS
 #define VRDX_NT_LAST_PASS 0
 #endif
+// Timing ablations of the pass kernels (tools/r05/ceiling.sh; results are WRONG by construction, 0 in the product), the ones
+// round 2 measured the formulation's ceiling with: 1 = no look-back (the prefix is taken as zero), 8 = the tile id is the
+// workgroup's index instead of a ticket, 256 = every tile writes its own key range (contiguous stores; the offset lookup
+// is still made).  257 / 265 = "what a pass would cost with the look-back (and the ticket) free".
+#ifndef VRDX_ABLATE
+#define VRDX_ABLATE 0
+#endif
 // Measurement switches of the MSD plan's kernels (tools/r05/ablate.sh builds the variants): VRDX_MSD_XCD = 0: tiles handed
 // out round-robin instead of in consecutive chunks per XCD; VRDX_MSD_NT_LOADS / VRDX_MSD_BUCKET_NT: non-temporal loads in
 // the scatter / the bucket kernel.
@@ -818,6 +825,10 @@ __device__ __forceinline__ void RankAtomic(const uint32_t (&key)[KPT], uint32_t 
         uint32_t old = 0;
         bool ranked = false;  // wave-uniform
         if (!uniform[c] && __popcll(others) <= 48) {
+          // (Round 5 tried the general form -- peel off up to FOUR groups with readlane / ballot, one adding lane per group
+          // -- for keys of a handful of distinct values: ~50 instructions per slot on all sixteen waves cost what the 16-way
+          // conflicts they avoid cost in the LDS, and the code they add made every watched input slower: four-valued keys at
+          // 2^25, passes 0 + 1: 201 us instead of 174, profiles/r05_adversarial_2pow25.txt.  Not adopted.)
           // A quarter of the lanes and more share the first lane's digit (never on random digits).  If everybody else is
           // ONE other digit -- a byte that is 0x00 | 0xFF (small signed integers), the top pass of dense sorted keys
           // (k and k + 2^24 side by side) -- the slot would serialise 32-way on two counters: 64 LDS cycles instead of 9,
@@ -1124,7 +1135,7 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   uint32_t key[KPT];
   const PassCounts<THREADS> passCounts = LoadPassCounts<THREADS>(a.histogramTable, tid);
-  if (tid == 0) misc[0] = atomicAdd(a.ticketCur, 1u);
+  if (tid == 0) misc[0] = (VRDX_ABLATE & 8) ? blockIdx.x : atomicAdd(a.ticketCur, 1u);
   PublishPassVotes<THREADS>(passCounts, n, a.hybridCap, tid, planFlags);
   // block sums (sorts of one round, four-pass plan only: the digit is the pass): every tile needs this pass's 256 global
   // counts for the digit base -- they are in the registers of the threads [256 * pass, 256 * pass + 256) already
@@ -1262,14 +1273,14 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
       exclusive += BlockPrefix<THREADS>(a.statusCur, a.blockCur, tile, tid, waveHist, a.failure, a.stickyFailure, a.spinLimit,
                                         &lookBackTrace);
   }
-  if (!blockSums && tile != 0)
+  if (!blockSums && tile != 0 && !(VRDX_ABLATE & 1))
     exclusive = LookBack<THREADS>(a.statusCur, tile, tid, waveHist, a.failure, a.stickyFailure, a.spinLimit, &lookBackTrace);
   TestDelayFirstTile(tile, a.spinLimit);
   if (tid < 256) {
     if (!lastTile && !blockSums)
       StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid],
                   (VRDX_FLAG_INCLUSIVE << VRDX_FLAG_SHIFT) | ((exclusive + count) & VRDX_VALUE_MASK));
-    tileOffset[tid] = exclusive - tileExclusive;
+    tileOffset[tid] = (VRDX_ABLATE & 256) ? tileStart : exclusive - tileExclusive;
   }
   LdsBarrier();
   VRDX_STAMP(5);
@@ -1376,7 +1387,7 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
   if (a.cap9 != 0 && *a.planWord == 3u) return;  // the nine-bit plan has taken the sort (see onesweep_kernel)
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   const PassCounts<THREADS> passCounts = LoadPassCounts<THREADS>(a.histogramTable, tid);
-  if (tid == 0) misc[0] = atomicAdd(a.ticketCur, 1u);
+  if (tid == 0) misc[0] = (VRDX_ABLATE & 8) ? blockIdx.x : atomicAdd(a.ticketCur, 1u);
   PublishPassVotes<THREADS>(passCounts, n, a.hybridCap, tid, misc + 1);
   // block sums (see onesweep_kernel): this pass's 256 global counts, parked in the idle staging buffer
   const bool blockSums = THREADS == 1024 && a.blockCur != nullptr;
@@ -1512,7 +1523,7 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
       exclusive += BlockPrefix<THREADS>(a.statusCur, a.blockCur, tile, tid, lookScratch, a.failure, a.stickyFailure,
                                         a.spinLimit, &lookBackTrace);
   }
-  if (!blockSums && tile != 0)
+  if (!blockSums && tile != 0 && !(VRDX_ABLATE & 1))
     exclusive = LookBack<THREADS>(a.statusCur, tile, tid, lookScratch, a.failure, a.stickyFailure, a.spinLimit,
                                   &lookBackTrace);
   TestDelayFirstTile(tile, a.spinLimit);
@@ -1520,8 +1531,8 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
     if (!lastTile && !blockSums)
       StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid],
                   (VRDX_FLAG_INCLUSIVE << VRDX_FLAG_SHIFT) | ((exclusive + countA + countB) & VRDX_VALUE_MASK));
-    offsetA[tid] = exclusive - localA;
-    offsetB[tid] = exclusive + countA - localB;
+    offsetA[tid] = (VRDX_ABLATE & 256) ? tileStart : exclusive - localA;
+    offsetB[tid] = (VRDX_ABLATE & 256) ? tileStart + sub : exclusive + countA - localB;
   }
   LdsBarrier();
   VRDX_STAMP(5);
@@ -2124,6 +2135,28 @@ __device__ __forceinline__ void ColumnBases(uint32_t* counters, uint32_t col, ui
   }
 }
 
+// Both in one sweep where the registers allow it (keys-only kernels): the column is read ONCE into `column`, its total
+// returned; ColumnBasesFrom then writes the bases from the registers -- sixteen LDS reads per thread and pass less.
+template <uint32_t ROW, int WAVES>
+__device__ __forceinline__ uint32_t ColumnRead(const uint32_t* counters, uint32_t col, uint32_t (&column)[WAVES]) {
+  uint32_t total = 0;
+#pragma unroll
+  for (int w = 0; w < WAVES; ++w) {
+    column[w] = counters[w * ROW + col];
+    total += column[w];
+  }
+  return total;
+}
+template <uint32_t ROW, int WAVES>
+__device__ __forceinline__ void ColumnBasesFrom(uint32_t* counters, uint32_t col, uint32_t add, const uint32_t (&column)[WAVES]) {
+  uint32_t running = add;
+#pragma unroll
+  for (int w = 0; w < WAVES; ++w) {
+    counters[w * ROW + col] = running;
+    running += column[w];
+  }
+}
+
 // ranks -> physical staging slots, in place: slot = StagingSlot(row[digit] + rank).  Reads only; the staging buffer may
 // alias the counters once every wave has been through here (the caller's barrier).
 template <int KPT, uint32_t STAGE, bool DYN>
@@ -2414,7 +2447,9 @@ __global__ __launch_bounds__(1024) void scatter_msd_kernel(MsdArgs a) {
   const uint32_t perXcd = gridDim.x / 8u;
   const uint32_t tile = VRDX_MSD_XCD ? (blockIdx.x % 8u) * perXcd + blockIdx.x / 8u : blockIdx.x;
   const uint32_t tileStart = tile * TILE;
-  // (loads first, verdict second: the keys fly while the overflow word arrives)
+  // Verdict first, loads second: a wave cannot end with loads in flight, so a launch that is turned down (a bucket beyond the
+  // capacity: the four passes behind it run) would still read every key -- 22 us at 2^25 for nothing, measured.
+  if (*a.overflowWord != 0u) return;
   const uint32_t valid = tile < a.tiles && tileStart < n ? ((n - tileStart) < TILE ? (n - tileStart) : TILE) : 0u;
   const uint32_t tileEnd = tileStart + valid;
   const uint32_t loadBase = tileStart + wave * (KPT * 64) + lane;
@@ -2426,7 +2461,6 @@ __global__ __launch_bounds__(1024) void scatter_msd_kernel(MsdArgs a) {
     base0 = a.bucketBase[2 * tid];
     base1 = a.bucketBase[2 * tid + 1];
   }
-  if (*a.overflowWord != 0u) return;  // a bucket beyond the capacity: the four passes behind this launch run
   if (blockIdx.x == 0 && tid == 0) *a.planWord = 3u;  // for the launches behind this one
   if (valid == 0) return;
 
@@ -2439,12 +2473,13 @@ __global__ __launch_bounds__(1024) void scatter_msd_kernel(MsdArgs a) {
   LdsBarrier();
 
   // tile histogram, tile-local bases, every wave's first position per digit
-  const uint32_t totals = (uint32_t)tid < ROW ? ColumnTotals<ROW, WAVES>(counters, tid) : 0u;
+  uint32_t column[WAVES];
+  const uint32_t totals = (uint32_t)tid < ROW ? ColumnRead<ROW, WAVES>(counters, tid, column) : 0u;
   const uint32_t count0 = totals & 0xFFFFu, count1 = totals >> 16;
   const uint32_t local0 = BlockExclusiveScanAll<THREADS>(count0 + count1, scanScratch, tid);
   const uint32_t local1 = local0 + count0;
   if ((uint32_t)tid < ROW) {
-    ColumnBases<ROW, WAVES>(counters, tid, local0 | (local1 << 16));
+    ColumnBasesFrom<ROW, WAVES>(counters, tid, local0 | (local1 << 16), column);
     tileOffset[2 * tid] = base0 + (prefixWord & 0xFFFFu) - local0;
     tileOffset[2 * tid + 1] = base1 + (prefixWord >> 16) - local1;
   }
@@ -2589,10 +2624,18 @@ __global__ __launch_bounds__(1024) void bucket_sort2_kernel(MsdArgs a) {
     LdsBarrier();
     uint32_t firstNow = first;  // (see SortInWorkgroup: keeps the read-back addresses out of registers across the passes)
     asm volatile("" : "+v"(firstNow));
-    const uint32_t totals = ColumnTotals<ROW, WAVES>(counters, tid);
-    const uint32_t count0 = totals & 0xFFFFu;
-    const uint32_t local0 = BlockExclusiveScanAll<THREADS>(count0 + (totals >> 16), scanScratch + 16 * pass, tid);
-    ColumnBases<ROW, WAVES>(counters, tid, local0 | ((local0 + count0) << 16));
+    if constexpr (!KV) {  // (key+value: the values are live as well; the column is read twice instead of kept)
+      uint32_t column[WAVES];
+      const uint32_t totals = ColumnRead<ROW, WAVES>(counters, tid, column);
+      const uint32_t count0 = totals & 0xFFFFu;
+      const uint32_t local0 = BlockExclusiveScanAll<THREADS>(count0 + (totals >> 16), scanScratch + 16 * pass, tid);
+      ColumnBasesFrom<ROW, WAVES>(counters, tid, local0 | ((local0 + count0) << 16), column);
+    } else {
+      const uint32_t totals = ColumnTotals<ROW, WAVES>(counters, tid);
+      const uint32_t count0 = totals & 0xFFFFu;
+      const uint32_t local0 = BlockExclusiveScanAll<THREADS>(count0 + (totals >> 16), scanScratch + 16 * pass, tid);
+      ColumnBases<ROW, WAVES>(counters, tid, local0 | ((local0 + count0) << 16));
+    }
     LdsBarrier();
     PositionsPacked16<KPT, TILE, DYN>(key, shift, mask, myRow, rank, slots);
     LdsBarrier();  // the counters are dead: the staging buffer takes their place
