@@ -62,11 +62,11 @@ int main() {
             ok = ok && (address + l9.inoutOffset) % 128 == 0 && l9.valuesOffset >= l9.inoutOffset + (uint64_t)n * 4;
           }
         }
-        // the MSD plan (MsdBits in vrdx_api.cpp: recorded from 16252929 elements up while the mean bucket of the top ten
+        // the MSD plan (MsdBits in vrdx_api.cpp: recorded from 8144129 / 16252929 elements up while the mean bucket of the top ten
         // -- or else eleven -- bits leaves 3 % of room in 36864, at most 2048 tiles of 32768 keys): its per-tile counts
         // (16 bits per tile and bucket) and its bucket table sit in front of the status regions of whatever passes are
         // recorded behind it, and all of it must fit at every alignment
-        if (g.keysPerThread == 32 && n >= 16252929u && vrdx::RoundUp(n, 32768u) <= 2048u) {
+        if (g.keysPerThread == 32 && n >= 8144129u && vrdx::RoundUp(n, 32768u) <= 2048u) {  // (keys-only from 8.14 M, key+value from 16.25 M)
           uint32_t bits = 0;
           for (uint32_t b = 10; b <= 11 && bits == 0; ++b)
             if ((((uint64_t)n + (1u << b) - 1) >> b) * 103 / 100 <= 36864) bits = b;
@@ -130,7 +130,7 @@ int main() {
           check((uint32_t)((int64_t)rounds * cus * capacity + d), true);
   check(VRDX_MAX_ELEMENTS, true);
   // the MSD plan's range: its first size, where it goes from ten to eleven bits, its last size, tile edges
-  for (uint32_t n : {16252929u, 16252930u, 35790291u, 35790292u, 36651000u, 67108863u, 67108864u, 67108865u})
+  for (uint32_t n : {8144129u, 8388608u, 16252929u, 16252930u, 35790291u, 35790292u, 36651000u, 67108863u, 67108864u, 67108865u})
     for (int d : {-32769, -32768, -1, 0, 1, 32767, 32768})
       check((uint32_t)((int64_t)n + d), true);
   std::printf("layout: %llu cases, %d failures\n", (unsigned long long)cases, failures);

@@ -87,7 +87,8 @@ def check_against_oracle(torch, sorter, oracle, keys, values=None, **kw):
         assert np.array_equal(gv, ev)
 
 
-MSD_FROM = 16_252_929   # vrdx_api.cpp MsdBits: sorts of this many elements and more record the MSD plan in front of the passes
+MSD_FROM = 16_252_929   # vrdx_api.cpp MsdBits: key+value sorts of this many elements and more record the MSD plan in front of the passes
+MSD_FROM_KEYS = 8_150_000   # ... keys-only sorts from the end of the eight-bit plan (8.1 M) up
 
 
 def decline_msd(keys):
@@ -96,7 +97,7 @@ def decline_msd(keys):
     beyond the plan's capacity of 36864 whether it scatters by ten or eleven bits -- and the device turns the plan down.
     The keys stay as good as uniform for everything else.  Returns keys (modified in place)."""
     n = len(keys)
-    if n >= MSD_FROM:
+    if n >= MSD_FROM_KEYS:
         step = max(1, n // 40000)
         keys[::step][:40000] = (keys[::step][:40000] & np.uint32(0x001FFFFF)) | np.uint32(0x2AC << 21)
     return keys
@@ -593,28 +594,30 @@ def test_nine_bit_hybrid_plan_and_its_fallback_at_the_sub_bucket_capacity(torch_
         k[where] = (k[where] & np.uint32(0x007FFFFF)) | np.uint32(0x155 << 23)   # ... except exactly `heavy` keys
         assert int(((k >> 23) == 0x155).sum()) == heavy
         ek, ep, _ = oracle.sort(k, iota)
-        kept = []
-        gk, _ = gpu_sort(torch_mod, sorter, k, storage_out=kept)
+        gk, _ = gpu_sort(torch_mod, sorter, k)   # (keys-only sorts of these sizes take the MSD plan since round 5)
         assert np.array_equal(gk, ek), heavy
+        kept = []
+        gk, gp = gpu_sort(torch_mod, sorter, k, iota, storage_out=kept)
+        assert np.array_equal(gk, ek) and np.array_equal(gp, ep), heavy
         verdict = int(kept[0][4:8].cpu().numpy().view(np.uint32)[0])
         assert (verdict == 3) == (heavy == cap), (heavy, verdict)
-        gk, gp = gpu_sort(torch_mod, sorter, k, iota)
-        assert np.array_equal(gk, ek) and np.array_equal(gp, ep), heavy
         count = n - n // 3
         ek, ep, _ = oracle.sort(k, iota, count=count)
         gk, gp = gpu_sort(torch_mod, sorter, k, iota, count=count, indirect=True, max_count=n)
         assert np.array_equal(gk, ek) and np.array_equal(gp, ep), heavy
 
 
-@pytest.mark.parametrize("n,key_value", [(MSD_FROM, False), (MSD_FROM, True), (20_000_003, True), (1 << 25, False),
-                                         (1 << 25, True), (36_500_000, False), (37_000_001, False), (45_000_000, True)])
+@pytest.mark.parametrize("n,key_value", [(MSD_FROM_KEYS, False), (ROUND, False), (12_000_001, False), (MSD_FROM, False),
+                                         (MSD_FROM, True), (20_000_003, True), (1 << 25, False), (1 << 25, True),
+                                         (36_500_000, False), (37_000_001, False), (45_000_000, True)])
 def test_msd_plan_and_its_fallback_at_the_bucket_capacity(torch_mod, sorter, oracle, n, key_value):
     """Sorts of 16.25 M elements and more record the MSD plan in front of their four passes (vrdx_kernels.hip, "MSD plan"):
     per-tile counts of the top ten or eleven bits, a spine, ONE stable scatter by those bits and one workgroup per bucket
     that sorts it by the remaining bits in two in-LDS passes; the DEVICE keeps the four passes when a bucket exceeds the
     capacity of 36864.  Uniform keys with ONE bucket brought to exactly 36864 elements (the plan applies: word 1 of the
     storage says 3) and to 36865 (it does not), keys-only or key+value (values = iota: the permutation itself), direct
-    and indirect with a smaller device-side count; the first size of the plan, the headline size, the last ten-bit and
+    and indirect with a smaller device-side count; the first sizes of the plan (keys-only: where the eight-bit plan ends,
+    8.1 M; key+value: where the nine-bit plan ends, 16.25 M), one round of tiles, the headline size, the last ten-bit and
     first eleven-bit sizes."""
     info = sorter.describe_plan(n, key_value)
     assert info.name == "msd" and info.bits == (10 if n <= 36_600_000 else 11), (info.name, info.bits)

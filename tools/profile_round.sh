@@ -31,7 +31,7 @@ F=$(find $OUT/pmc_fetch -name '*counter_collection.csv' | head -1)
 W=$(find $OUT/pmc_write -name '*counter_collection.csv' | head -1)
 python3 tools/pmc_report.py "$F" "$W" 33554432 $OUT/pmc_traffic.json > $OUT/pmc_report.log 2>&1
 # 4. native sweep over N (the reference's curve: bench/bench.cc:17-20)
-timeout 600 tests/native/vrdx_selftest bench 15 16 17 18 19 20 21 22 23 24 25 > $OUT/native_sweep.txt 2>&1
+timeout 900 tests/native/vrdx_selftest bench 15 16 17 18 19 20 21 22 23 24 25 26 27 > $OUT/native_sweep.txt 2>&1
 ls -R $OUT | head -40
 # 5. the rest of the round's evidence: adversarial inputs at 2^25, a soak of overlapping sorts, the bench driver's sweep
 #    (hip and rocprim backends), the smoke entry and the GPU test log

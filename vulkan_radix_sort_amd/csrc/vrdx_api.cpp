@@ -231,7 +231,7 @@ uint32_t Hybrid9Capacity(bool atomicRank, uint32_t elementCount, uint32_t hybrid
 // records it from n elements up instead (measurements: below its default range it replaces the other two plans).
 uint32_t MsdTileKeys(uint32_t) { return vrdx::kMsdTileKeys; }
 
-uint32_t MsdBits(bool atomicRank, bool keyValue, uint32_t elementCount, uint32_t* capacity) {
+uint32_t MsdBits(bool atomicRank, bool keyValue, uint32_t elementCount, uint32_t hybridCap, uint32_t* capacity) {
   static const bool enabled = [] {
     const char* all = std::getenv("VRDX_HYBRID");
     const char* msd = std::getenv("VRDX_MSD");
@@ -241,7 +241,11 @@ uint32_t MsdBits(bool atomicRank, bool keyValue, uint32_t elementCount, uint32_t
   static const int forcedBits = TuningKnob("VRDX_MSD_BITS");  // measurements: 10 | 11 wherever the capacity allows
   static const int knobLast = TuningKnob("VRDX_HYBRID_HEADROOM_LAST");
   if (!enabled || !atomicRank) return 0;
-  const uint32_t lowest = from > 0 ? (uint32_t)from : 16252929u;  // where the nine-bit plan ends
+  // Key+value: from where the nine-bit plan ends (16.2 M: below, that plan is 3-6 % faster for pairs).  Keys-only: from
+  // where the EIGHT-bit plan ends (8.1 M: hybridCap == 0) -- with two of its fallback's launches folded into its own it is
+  // 6 % faster than the four passes at one round of tiles, within 2 % of the nine-bit plan up to 11.5 M and 1-4 % faster
+  // from there on (profiles/r05_msd_threshold_sweep.txt), so keys-only sorts no longer record the nine-bit plan at all.
+  const uint32_t lowest = from > 0 ? (uint32_t)from : (keyValue ? 16252929u : (hybridCap == 0 ? vrdx::kSmallSortMaxElements + 1u : ~0u));
   if (elementCount < lowest || vrdx::RoundUp(elementCount, vrdx::kMsdTileKeys) > vrdx::kMsdMaxTiles) return 0;
   const uint32_t cap = keyValue ? vrdx::kMsdCapKeyValue : vrdx::kMsdCapKeys;
   *capacity = cap;
@@ -357,8 +361,9 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
 
   const bool atomicRank = sorter->atomicRank.load(std::memory_order_relaxed);  // one answer for the whole sort
   uint32_t msdCap = 0;
-  uint32_t msdBits = ForcedConfigIndex() < 0 ? MsdBits(atomicRank, keyValue, elementCount, &msdCap) : 0u;
-  const uint32_t hybridCap = ForcedConfigIndex() < 0 && msdBits == 0 ? HybridCapacity(atomicRank, elementCount) : 0u;
+  const uint32_t hybridCap = ForcedConfigIndex() < 0 ? HybridCapacity(atomicRank, elementCount) : 0u;
+  uint32_t msdBits = ForcedConfigIndex() < 0 ? MsdBits(atomicRank, keyValue, elementCount, hybridCap, &msdCap) : 0u;
+  if (hybridCap != 0) msdBits = 0;  // (VRDX_MSD_FROM below the eight-bit plan's end: that plan keeps its sizes)
   uint32_t cap9 = ForcedConfigIndex() < 0 && msdBits == 0
                       ? Hybrid9Capacity(atomicRank, elementCount, hybridCap, (uint32_t)sorter->computeUnits)
                       : 0u;
@@ -531,71 +536,8 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     b.top9Table = top9Table;
     EnqueueCheck(sorter, "bucket_sort_kernel (nine-bit)", vrdx::LaunchBucketSort9(stream, keyValue, b));
   }
-  // The MSD plan, recorded in front of the passes like the nine-bit plan: spine (prefixes over the tiles, bucket table,
-  // verdict), scatter by the top bits, one workgroup per bucket.  The passes behind return on the verdict word.
-  if (msdBits != 0) {
-    vrdx::MsdArgs m;
-    std::memset(&m, 0, sizeof(m));
-    m.keysCaller = keys;
-    m.keysScratch = keysScratch;
-    m.valuesCaller = keyValue ? values : nullptr;
-    m.valuesScratch = keyValue ? valuesScratch : nullptr;
-    m.maxCount = elementCount;
-    m.countPtr = countPtr;
-    m.histogramTable = globalHistogram;
-    m.tileCounts = reinterpret_cast<uint32_t*>(storage + layout.msdCountsOffset);
-    m.bucketBase = reinterpret_cast<uint32_t*>(storage + layout.msdBucketOffset);
-    m.bucketCount = m.bucketBase + ((size_t)1 << msdBits);
-    m.overflowWord = reinterpret_cast<uint32_t*>(storage + VRDX_OFF_MSD_OVERFLOW);
-    m.planWord = reinterpret_cast<uint32_t*>(storage + VRDX_OFF_PLAN);
-    m.bits = msdBits;
-    m.cap = msdCap;
-    m.tiles = msdTiles;
-    m.tileKeys = msdTileKeys;
-    // Timestamps: the plan's own three stages take the names they have in the reference -- slot 2 "upsweep" = the
-    // histogram, 3 "spine", 4 "downsweep" = the scatter -- and the bucket sorts are pass 1's "upsweep" (slot 5, like the
-    // eight-bit plan's); the four returning passes share the slots behind.
-    Stamp(pool, query + 2, stream);
-    EnqueueCheck(sorter, "spine_msd_kernel", vrdx::LaunchSpineMsd(stream, m));
-    Stamp(pool, query + 3, stream);
-    EnqueueCheck(sorter, "scatter_msd_kernel", vrdx::LaunchScatterMsd(stream, keyValue, m));
-    Stamp(pool, query + 4, stream);
-    EnqueueCheck(sorter, "bucket_sort2_kernel", vrdx::LaunchBucketSort2(stream, keyValue, m));
-    Stamp(pool, query + 5, stream);
-  }
-  for (uint32_t pass = 0; pass < VRDX_PASSES; ++pass) {
-    // "upsweep" of this pass: the fused histogram kernel for pass 0, nothing for the others -- the same
-    // point of the stream as the previous pass's "downsweep" stamp
-    if (msdBits != 0) {
-      // (slots 2-5 are the MSD plan's, above; launch 0 and launch 1 fall into slot 7)
-      if (pass == 1) StampSame(pool, query + 6, query + 5);
-      if (pass >= 2) {
-        StampSame(pool, query + 2 + 3 * pass + 0, query + 2 + 3 * (pass - 1) + 2);
-        StampSame(pool, query + 2 + 3 * pass + 1, query + 2 + 3 * pass + 0);
-      }
-    } else if (pass == 0) {
-      Stamp(pool, query + 2, stream);
-    } else if (pass == 1 && hybridCap != 0) {
-      // the hybrid plan's second half, between launch 0 and launch 1 (which is empty when the plan applies): its time
-      // is this pass's "upsweep" slot
-      vrdx::BucketSortArgs b;
-      b.keysScratch = keysScratch;
-      b.keysCaller = keys;
-      b.valuesScratch = keyValue ? valuesScratch : nullptr;
-      b.valuesCaller = keyValue ? values : nullptr;
-      b.maxCount = elementCount;
-      b.countPtr = countPtr;
-      b.histogramTable = globalHistogram;
-      b.hybridCap = hybridCap;
-      b.planWord = reinterpret_cast<const uint32_t*>(storage + VRDX_OFF_PLAN);
-      b.top9Table = nullptr;
-      EnqueueCheck(sorter, "bucket_sort_kernel", vrdx::LaunchBucketSort(stream, keyValue, atomicRank, b));
-      Stamp(pool, query + 2 + 3 * pass + 0, stream);
-    } else {
-      StampSame(pool, query + 2 + 3 * pass + 0, query + 2 + 3 * (pass - 1) + 2);
-    }
-    if (msdBits == 0) StampSame(pool, query + 2 + 3 * pass + 1, query + 2 + 3 * pass + 0);  // "spine" (fused into the look-back)
-
+  // the arguments of pass `pass` of the four passes (also handed to the MSD plan's launches, whose second role they are)
+  auto passArgs = [&](uint32_t pass) {
     vrdx::OnesweepArgs args;
     // which pair of arrays the pass reads is settled on the device (vrdx_kernels.h); the reference
     // switches in->out to out->in for pass 1, pass 3 (:417-427) and so do four ranking passes here
@@ -640,6 +582,94 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
 #ifdef VRDX_TRACE
     args.trace = TraceBuffer(pass, tiles);
 #endif
+    return args;
+  };
+  bool msdFused = false;
+  // The MSD plan, recorded in front of the passes like the nine-bit plan: spine (prefixes over the tiles, bucket table,
+  // verdict), scatter by the top bits, one workgroup per bucket.  The passes behind return on the verdict word.
+  if (msdBits != 0) {
+    vrdx::MsdArgs m;
+    std::memset(&m, 0, sizeof(m));
+    m.keysCaller = keys;
+    m.keysScratch = keysScratch;
+    m.valuesCaller = keyValue ? values : nullptr;
+    m.valuesScratch = keyValue ? valuesScratch : nullptr;
+    m.maxCount = elementCount;
+    m.countPtr = countPtr;
+    m.histogramTable = globalHistogram;
+    m.tileCounts = reinterpret_cast<uint32_t*>(storage + layout.msdCountsOffset);
+    m.bucketBase = reinterpret_cast<uint32_t*>(storage + layout.msdBucketOffset);
+    m.bucketCount = m.bucketBase + ((size_t)1 << msdBits);
+    m.overflowWord = reinterpret_cast<uint32_t*>(storage + VRDX_OFF_MSD_OVERFLOW);
+    m.planWord = reinterpret_cast<uint32_t*>(storage + VRDX_OFF_PLAN);
+    m.bits = msdBits;
+    m.cap = msdCap;
+    m.tiles = msdTiles;
+    m.tileKeys = msdTileKeys;
+    // Timestamps: the plan's own three stages take the names they have in the reference -- slot 2 "upsweep" = the
+    // histogram, 3 "spine", 4 "downsweep" = the scatter -- and the bucket sorts are pass 1's "upsweep" (slot 5, like the
+    // eight-bit plan's); the four returning passes share the slots behind.
+    Stamp(pool, query + 2, stream);
+    EnqueueCheck(sorter, "spine_msd_kernel", vrdx::LaunchSpineMsd(stream, m));
+    Stamp(pool, query + 3, stream);
+    // The scatter launch is ALSO pass 0 of the fallback and the bucket launch pass 1 (one branch on the verdict, on the
+    // device): only passes 2 and 3 remain as launches that return when the plan runs.  The fused kernels exist for the
+    // geometry the recorder selects at these sizes (ConfigIndex: the two-sub-tile kernel).
+    // Keys-only sorts (the key+value form measured slower than the launches it saves, vrdx_kernels.hip).
+    msdFused = !keyValue && configIndex == kCfg1024x32x2 && TuningKnob("VRDX_MSD_FUSED") != 0;
+    if (msdFused) {
+      EnqueueCheck(sorter, "msd_scatter_or_pass0_kernel", vrdx::LaunchMsdFused(stream, false, keyValue, m, passArgs(0), tilePlan.tiles));
+      Stamp(pool, query + 4, stream);
+      EnqueueCheck(sorter, "msd_buckets_or_pass1_kernel", vrdx::LaunchMsdFused(stream, true, keyValue, m, passArgs(1), tilePlan.tiles));
+      Stamp(pool, query + 5, stream);
+    } else {
+      EnqueueCheck(sorter, "scatter_msd_kernel", vrdx::LaunchScatterMsd(stream, keyValue, m));
+      Stamp(pool, query + 4, stream);
+      EnqueueCheck(sorter, "bucket_sort2_kernel", vrdx::LaunchBucketSort2(stream, keyValue, m));
+      Stamp(pool, query + 5, stream);
+    }
+  }
+  for (uint32_t pass = 0; pass < VRDX_PASSES; ++pass) {
+    if (msdFused && pass < 2) {  // these two ran (or returned) inside the plan's own launches
+      if (pass == 1) {
+        StampSame(pool, query + 6, query + 5);
+        StampSame(pool, query + 7, query + 5);
+      }
+      continue;
+    }
+    // "upsweep" of this pass: the fused histogram kernel for pass 0, nothing for the others -- the same
+    // point of the stream as the previous pass's "downsweep" stamp
+    if (msdBits != 0) {
+      // (slots 2-5 are the MSD plan's, above; launch 0 and launch 1 fall into slot 7)
+      if (pass == 1) StampSame(pool, query + 6, query + 5);
+      if (pass >= 2) {
+        StampSame(pool, query + 2 + 3 * pass + 0, query + 2 + 3 * (pass - 1) + 2);
+        StampSame(pool, query + 2 + 3 * pass + 1, query + 2 + 3 * pass + 0);
+      }
+    } else if (pass == 0) {
+      Stamp(pool, query + 2, stream);
+    } else if (pass == 1 && hybridCap != 0) {
+      // the hybrid plan's second half, between launch 0 and launch 1 (which is empty when the plan applies): its time
+      // is this pass's "upsweep" slot
+      vrdx::BucketSortArgs b;
+      b.keysScratch = keysScratch;
+      b.keysCaller = keys;
+      b.valuesScratch = keyValue ? valuesScratch : nullptr;
+      b.valuesCaller = keyValue ? values : nullptr;
+      b.maxCount = elementCount;
+      b.countPtr = countPtr;
+      b.histogramTable = globalHistogram;
+      b.hybridCap = hybridCap;
+      b.planWord = reinterpret_cast<const uint32_t*>(storage + VRDX_OFF_PLAN);
+      b.top9Table = nullptr;
+      EnqueueCheck(sorter, "bucket_sort_kernel", vrdx::LaunchBucketSort(stream, keyValue, atomicRank, b));
+      Stamp(pool, query + 2 + 3 * pass + 0, stream);
+    } else {
+      StampSame(pool, query + 2 + 3 * pass + 0, query + 2 + 3 * (pass - 1) + 2);
+    }
+    if (msdBits == 0) StampSame(pool, query + 2 + 3 * pass + 1, query + 2 + 3 * pass + 0);  // "spine" (fused into the look-back)
+
+    const vrdx::OnesweepArgs args = passArgs(pass);
     EnqueueCheck(sorter, "onesweep_kernel",
                  vrdx::LaunchOnesweep(stream, configIndex, tiles, keyValue, atomicRank, args));
 
@@ -981,15 +1011,15 @@ void vrdxHipDescribePlan(VrdxSorter sorter, uint32_t elementCount, int keyValue,
     return;
   }
   uint32_t msdCap = 0;
-  const uint32_t msdBits = adaptive ? MsdBits(atomicRank, kv, elementCount, &msdCap) : 0u;
-  const uint32_t hybridCap = adaptive && msdBits == 0 ? HybridCapacity(atomicRank, elementCount) : 0u;
+  const uint32_t hybridCap = adaptive ? HybridCapacity(atomicRank, elementCount) : 0u;
+  const uint32_t msdBits = adaptive && hybridCap == 0 ? MsdBits(atomicRank, kv, elementCount, hybridCap, &msdCap) : 0u;
   const uint32_t cap9 =
       adaptive && msdBits == 0 ? Hybrid9Capacity(atomicRank, elementCount, hybridCap, (uint32_t)sorter->computeUnits) : 0u;
   if (msdBits != 0) {
     info->plan = VRDX_HIP_PLAN_MSD;
     info->bits = msdBits;
     info->bytesPerElement = twoTrips;
-    info->launches = 8;  // histogram, spine, scatter, buckets, four returning passes
+    info->launches = kv ? 8u : 6u;  // histogram, spine, scatter, buckets, four returning passes (keys-only: two of them folded into the plan's launches)
   } else if (cap9 != 0) {
     info->plan = VRDX_HIP_PLAN_HYBRID9;
     info->bits = 9;

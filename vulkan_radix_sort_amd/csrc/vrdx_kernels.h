@@ -182,6 +182,12 @@ hipError_t LaunchHistogramMsd(hipStream_t stream, uint32_t grid, const uint32_t*
 hipError_t LaunchSpineMsd(hipStream_t stream, const MsdArgs& args);
 hipError_t LaunchScatterMsd(hipStream_t stream, bool keyValue, const MsdArgs& args);
 hipError_t LaunchBucketSort2(hipStream_t stream, bool keyValue, const MsdArgs& args);
+// The scatter (bucketLaunch = false) or bucket (true) launch of the plan with pass 0 / pass 1 of its fallback as a second
+// role, chosen on the device by the plan's verdict: saves two of the four returning launches.  `pass` = the arguments and
+// passGrid the grid LaunchOnesweep would have been given for that pass (the two-sub-tile kernel keys-only, 1024x32
+// key+value; one-atomic ranking).
+hipError_t LaunchMsdFused(hipStream_t stream, bool bucketLaunch, bool keyValue, const MsdArgs& args, const OnesweepArgs& pass,
+                          uint32_t passGrid);
 
 // Runs the device self-check of the LDS same-address atomic ordering on the current device
 // (synchronous, ~1 ms).  *laneOrdered = true when returning atomics are served in lane order.

@@ -71,6 +71,9 @@ namespace vrdx {
 #ifndef VRDX_MSD_BUCKET_NT
 #define VRDX_MSD_BUCKET_NT 0
 #endif
+#ifndef VRDX_MSD_OUT_NT
+#define VRDX_MSD_OUT_NT 0  // the bucket kernel's output stores non-temporal (measurement)
+#endif
 
 
 // Timing-only phase trace for tools/trace.sh (never defined in the product build): thread 0 of
@@ -1092,7 +1095,7 @@ constexpr int MinWavesPerSimd() {
 // 64 keys, a tile is a.slots * THREADS keys, and the loops over the slots stop there, so that a tile costs what its
 // keys cost.  The waves still cover the tile in memory order, pads (the sort's last tile only) still sit at its end.
 template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK, bool DYN>
-__global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void onesweep_kernel(OnesweepArgs a) {
+__device__ __forceinline__ void OnesweepBody(const OnesweepArgs a) {
   constexpr int WAVES = THREADS / 64;
   constexpr uint32_t TILE = THREADS * KPT;
   static_assert(THREADS >= 256 && THREADS % 256 == 0, "one thread per digit, whole look-back groups");
@@ -1323,6 +1326,11 @@ __global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void on
 #endif
 }
 
+template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK, bool DYN>
+__global__ __launch_bounds__(THREADS, (MinWavesPerSimd<THREADS, KPT>())) void onesweep_kernel(OnesweepArgs a) {
+  OnesweepBody<THREADS, KPT, KV, ATOMIC_RANK, DYN>(a);
+}
+
 // ---------------------------------------------------------------------------------------------
 // onesweep_pair_kernel: one workgroup = TWO consecutive sub-tiles of THREADS*KPT keys, ONE status
 // row, ONE ticket and ONE look-back for both.
@@ -1358,7 +1366,7 @@ constexpr int PairMinWavesPerSimd() {
 }
 
 template <int THREADS, int KPT, bool DYN>  // DYN: even-split tiles, see onesweep_kernel
-__global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) void onesweep_pair_kernel(OnesweepArgs a) {
+__device__ __forceinline__ void OnesweepPairBody(const OnesweepArgs a) {
   constexpr int WAVES = THREADS / 64;
   constexpr int GROUPS = THREADS / 256;
   constexpr uint32_t SUB = THREADS * KPT;  // keys per sub-tile == staging buffer words
@@ -1561,6 +1569,11 @@ __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) voi
     for (int i = 0; i < 8; ++i) a.trace[(size_t)tile * 8 + i] = stamps[i];
   }
 #endif
+}
+
+template <int THREADS, int KPT, bool DYN>
+__global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) void onesweep_pair_kernel(OnesweepArgs a) {
+  OnesweepPairBody<THREADS, KPT, DYN>(a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2429,7 +2442,7 @@ constexpr size_t ScatterMsdLdsWords() {
 }
 
 template <uint32_t BITS, bool KV>
-__global__ __launch_bounds__(1024) void scatter_msd_kernel(MsdArgs a) {
+__device__ __forceinline__ void ScatterMsdBody(const MsdArgs a) {
   constexpr int THREADS = 1024, KPT = 32, WAVES = THREADS / 64;
   constexpr uint32_t TILE = kMsdTileKeys, D = 1u << BITS, SHIFT = 32u - BITS, MASK = D - 1u, ROW = D / 2u;
   static_assert(THREADS * KPT == TILE && ROW <= (uint32_t)THREADS && WAVES * ROW <= TILE, "geometry");
@@ -2571,7 +2584,7 @@ constexpr size_t BucketSort2LdsWords() {
 }
 
 template <uint32_t BITS, int KPT, bool KV>
-__global__ __launch_bounds__(1024) void bucket_sort2_kernel(MsdArgs a) {
+__device__ __forceinline__ void BucketSort2Body(const MsdArgs a) {
   constexpr int THREADS = 1024, WAVES = THREADS / 64;
   constexpr uint32_t TILE = THREADS * KPT;
   constexpr uint32_t W0 = 11u, W1 = 32u - BITS - W0;
@@ -2671,10 +2684,66 @@ __global__ __launch_bounds__(1024) void bucket_sort2_kernel(MsdArgs a) {
     if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
     const uint32_t index = first + 64 * i;
     if (index < n) {
-      keysOut[index] = key[i];
-      if constexpr (KV) valuesOut[index] = val[i];
+      if (VRDX_MSD_OUT_NT) {
+        __builtin_nontemporal_store(key[i], &keysOut[index]);
+        if constexpr (KV) __builtin_nontemporal_store(val[i], &valuesOut[index]);
+      } else {
+        keysOut[index] = key[i];
+        if constexpr (KV) valuesOut[index] = val[i];
+      }
     }
   }
+}
+
+template <uint32_t BITS, bool KV>
+__global__ __launch_bounds__(1024) void scatter_msd_kernel(MsdArgs a) {
+  ScatterMsdBody<BITS, KV>(a);
+}
+template <uint32_t BITS, int KPT, bool KV>
+__global__ __launch_bounds__(1024) void bucket_sort2_kernel(MsdArgs a) {
+  BucketSort2Body<BITS, KPT, KV>(a);
+}
+
+// ---- the plan's launches double as the first two launches of its fallback ------------------------------
+// Behind the MSD plan the four passes are recorded as the fallback for keys the device turns the plan down for; when the plan
+// runs they return on the verdict word -- 4.1 us each at 2^25 (512 workgroups of 156 KiB of LDS and one load), 16 us of a
+// 260 us sort.  Two of the four are saved by giving the plan's own launches a second ROLE: the scatter launch is pass 0 of
+// the fallback when a bucket exceeds the capacity, the bucket launch is pass 1 when the scatter has not run -- one branch on
+// a word every workgroup reads anyway, the grid the larger of the two roles' (a workgroup beyond its role's range returns:
+// both bodies check).  The pass is the one the recorder would have launched at these sizes: the two-sub-tile kernel
+// keys-only, the one-atomic ranking (the plan is recorded with it only), DYN by the tile plan.  Passes 2 and 3 stay launches
+// of their own.  KEYS-ONLY sorts only: 0.2520 instead of 0.2610 ms at 2^25.  The key+value form (the plan's kernels fused with
+// onesweep_kernel<1024, 32, kv>) was built and measured as well: its scatter role ran 16 us SLOWER than scatter_msd_kernel
+// alone (163.6 against 147.6 us; the compiler leaves it a private segment of 36 bytes that no instruction touches, and with
+// it a scratch set-up per wave) -- more than the two launches save.  Not instantiated.
+template <uint32_t BITS, bool KV, bool DYN>
+__device__ __forceinline__ void FallbackPassBody(const OnesweepArgs p) {
+  if constexpr (KV)
+    OnesweepBody<1024, 32, true, true, DYN>(p);
+  else
+    OnesweepPairBody<1024, 32, DYN>(p);
+}
+template <bool KV>
+constexpr size_t MsdFusedLdsWords(uint32_t bits, bool bucketLaunch) {
+  const size_t pass = KV ? OnesweepLdsWords<1024, 32, true>() : PairLdsWords<1024, 32>();
+  const size_t plan = bucketLaunch ? BucketSort2LdsWords<(KV ? kMsdCapKeyValue : kMsdCapKeys) / 1024>()
+                                   : (size_t)kMsdTileKeys + ((size_t)1 << bits) + 32;
+  return pass > plan ? pass : plan;
+}
+
+template <uint32_t BITS, bool KV, bool DYN>
+__global__ __launch_bounds__(1024) void msd_scatter_or_pass0_kernel(MsdArgs m, OnesweepArgs p) {
+  if (*m.overflowWord == 0u)
+    ScatterMsdBody<BITS, KV>(m);
+  else
+    FallbackPassBody<BITS, KV, DYN>(p);
+}
+template <uint32_t BITS, bool KV, bool DYN>
+__global__ __launch_bounds__(1024) void msd_buckets_or_pass1_kernel(MsdArgs m, OnesweepArgs p) {
+  if (*m.planWord == 3u)
+    BucketSort2Body<BITS, (KV ? kMsdCapKeyValue : kMsdCapKeys) / 1024, KV>(m);
+  else
+    FallbackPassBody<BITS, KV, DYN>(p);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3129,6 +3198,19 @@ static hipError_t PrepareMsdBits() {
     const hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.bytes);
     if (e != hipSuccess) return e;
   }
+  const struct {
+    const void* fn;
+    size_t bytes;
+  } fused[] = {
+      {reinterpret_cast<const void*>(&msd_scatter_or_pass0_kernel<BITS, false, false>), MsdFusedLdsWords<false>(BITS, false) * 4},
+      {reinterpret_cast<const void*>(&msd_scatter_or_pass0_kernel<BITS, false, true>), MsdFusedLdsWords<false>(BITS, false) * 4},
+      {reinterpret_cast<const void*>(&msd_buckets_or_pass1_kernel<BITS, false, false>), MsdFusedLdsWords<false>(BITS, true) * 4},
+      {reinterpret_cast<const void*>(&msd_buckets_or_pass1_kernel<BITS, false, true>), MsdFusedLdsWords<false>(BITS, true) * 4},
+  };
+  for (const auto& k : fused) {
+    const hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.bytes);
+    if (e != hipSuccess) return e;
+  }
   return hipSuccess;
 }
 
@@ -3203,6 +3285,28 @@ hipError_t LaunchBucketSort2(hipStream_t stream, bool keyValue, const MsdArgs& a
     return hipErrorInvalidValue;
   const size_t lds = (keyValue ? BucketSort2LdsWords<kPairs>() : BucketSort2LdsWords<kKeys>()) * 4;
   return Launch(kernel, 1u << args.bits, 1024, lds, stream, args);
+}
+
+// The plan's scatter / bucket launch with the fallback's pass 0 / pass 1 as its second role (bucketLaunch selects which).
+// passGrid: the grid LaunchOnesweep would have used for that pass.
+template <uint32_t BITS, bool KV>
+static hipError_t LaunchMsdFusedBits(hipStream_t stream, bool bucketLaunch, const MsdArgs& m, const OnesweepArgs& p, uint32_t passGrid) {
+  const bool dyn = p.slots != 0;
+  const void* kernel =
+      bucketLaunch ? (dyn ? reinterpret_cast<const void*>(&msd_buckets_or_pass1_kernel<BITS, KV, true>)
+                          : reinterpret_cast<const void*>(&msd_buckets_or_pass1_kernel<BITS, KV, false>))
+                   : (dyn ? reinterpret_cast<const void*>(&msd_scatter_or_pass0_kernel<BITS, KV, true>)
+                          : reinterpret_cast<const void*>(&msd_scatter_or_pass0_kernel<BITS, KV, false>));
+  const uint32_t planGrid = bucketLaunch ? (1u << BITS) : 8u * ((m.tiles + 7u) / 8u);
+  return Launch(kernel, planGrid > passGrid ? planGrid : passGrid, 1024, MsdFusedLdsWords<KV>(BITS, bucketLaunch) * 4, stream, m, p);
+}
+
+hipError_t LaunchMsdFused(hipStream_t stream, bool bucketLaunch, bool keyValue, const MsdArgs& m, const OnesweepArgs& p,
+                          uint32_t passGrid) {
+  if (keyValue || m.tileKeys != kMsdTileKeys || m.cap != kMsdCapKeys) return hipErrorInvalidValue;  // keys-only sorts only
+  if (m.bits == 10) return LaunchMsdFusedBits<10, false>(stream, bucketLaunch, m, p, passGrid);
+  if (m.bits == 11) return LaunchMsdFusedBits<11, false>(stream, bucketLaunch, m, p, passGrid);
+  return hipErrorInvalidValue;
 }
 
 hipError_t LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool keyValue, bool atomicRank,
