@@ -509,12 +509,16 @@ def main():
         plan = sorter.describe_plan(n, key_value)
         item = 8.0 if key_value else 4.0   # bytes of one element (key [+ value]) in one direction
         if plan.name == "msd":
-            kv_arg = "true" if key_value else "false"
             names = {"histogram": "histogram_msd_kernel<32u, %du, 2u>" % plan.bits,
                      "spine": "spine_msd_kernel<%du>" % plan.bits,
-                     "scatter": "scatter_msd_kernel<%du, 32, %s>" % (plan.bits, kv_arg),
-                     "bucket": "bucket_sort2_kernel<%du, 36, %s, %s>" % (plan.bits, kv_arg, "false" if key_value else "true"),
-                     "fallback": "4 x " + kernel_name(version, "key-value" if key_value else "keys") + " (returning on the verdict)"}
+                     # keys-only: the plan's scatter / bucket launches are also pass 0 / pass 1 of the fallback (one kernel,
+                     # two roles chosen on the device); two passes remain as launches that return on the verdict
+                     "scatter": ("scatter_msd_kernel<%du, true>" % plan.bits) if key_value
+                                else ("msd_scatter_or_pass0_kernel<%du, false, false>" % plan.bits),
+                     "bucket": ("bucket_sort2_kernel<%du, 36, true>" % plan.bits) if key_value
+                               else ("msd_buckets_or_pass1_kernel<%du, false, false>" % plan.bits),
+                     "fallback": ("4 x " if key_value else "2 x ") + kernel_name(version, "key-value" if key_value else "keys")
+                                 + " (returning on the verdict)"}
             bytes_of = {"histogram": 4.0 * n, "spine": 0.0, "scatter": 2 * item * n, "bucket": 2 * item * n, "fallback": 0.0}
             what = {"histogram": "HBM read", "spine": "launch latency (4 MiB of 16-bit counts)",
                     "scatter": "HBM read + write in runs of 128 bytes", "bucket": "LDS (two in-LDS passes per key between one read and one write)",

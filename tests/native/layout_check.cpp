@@ -70,7 +70,10 @@ int main() {
           uint32_t bits = 0;
           for (uint32_t b = 10; b <= 11 && bits == 0; ++b)
             if ((((uint64_t)n + (1u << b) - 1) >> b) * 103 / 100 <= 36864) bits = b;
-          const uint64_t msdTiles = vrdx::RoundUp(n, 32768u);
+          // (equal tiles filling whole rounds of one workgroup per CU: up to rounds x cus of them)
+          const uint32_t msdTileKeys = vrdx::MsdTileKeysFor(n, cus, 2048u);
+          const uint64_t msdTiles = vrdx::RoundUp(n, msdTileKeys);
+          ok = ok && msdTileKeys % 4096u == 0 && msdTileKeys >= 4096u && msdTileKeys <= 32768u && msdTiles <= 2048u;
           for (uint32_t address = 0; bits != 0 && address < 128; address += 16) {
             const vrdx::StorageLayout lm = vrdx::MakeLayout(n, VRDX_STORAGE_ALIGN, plan.tiles, 0x7f0000001000ull + address,
                                                             plan.blockSums, 0, bits, msdTiles);

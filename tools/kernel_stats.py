@@ -25,7 +25,7 @@ if "--json" in sys.argv:
     import vulkan_radix_sort_amd as vrdx
     out = sys.argv[sys.argv.index("--json") + 1]
     with open(out, "w") as f:
-        json.dump({"file": os.path.basename(sys.argv[1]), "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py",
+        json.dump({"file": os.path.basename(sys.argv[1]), "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-sweep",
                    "measured_on": os.uname().nodename,
                    "kernel_source_sha256": bench.kernel_source_digest(), "library": vrdx.version_string(),
                    "kernels": rows}, f, indent=1)

@@ -72,11 +72,13 @@ def main():
             # onesweep_kernel<THREADS, KPT, KV, ATOMIC_RANK, DYN>: third argument; onesweep_pair_kernel<THREADS, KPT, DYN> is keys-only
             targs = [t.strip() for t in name.split("<", 1)[1].split(">", 1)[0].split(",")]
             kind = "key_value" if "pair" not in name and len(targs) > 2 and targs[2] == "true" else "keys"
-        elif "scatter_msd" in name or "bucket_sort2" in name:
+        elif "scatter_msd" in name or "bucket_sort2" in name or "msd_scatter_or_pass0" in name or "msd_buckets_or_pass1" in name:
             # the MSD plan's kernels: 4-byte loads; the scatter stores quads (16 B), the bucket kernel words
+            # scatter_msd_kernel<BITS, KV> | bucket_sort2_kernel<BITS, KPT, KV> | msd_*_or_pass*_kernel<BITS, KV, DYN> (keys-only)
             targs = [t.strip() for t in name.split("<", 1)[1].split(">", 1)[0].split(",")]
-            mode = "key_value" if targs[2] == "true" else "keys"
-            part = "scatter" if "scatter_msd" in name else "bucket"
+            kv_arg = targs[2] if "bucket_sort2" in name else targs[1]
+            mode = "key_value" if kv_arg == "true" else "keys"
+            part = "scatter" if "scatter" in name else "bucket"
             rd = fetch[name] * f4
             wr = write.get(name, 0.0) * (w16 if part == "scatter" else w4)
             kind = "msd_%s_%s" % (part, mode)

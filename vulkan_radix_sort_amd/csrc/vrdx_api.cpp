@@ -102,7 +102,8 @@ enum : int { kCfg1024x8 = 0, kCfg1024x16 = 1, kCfg1024x32 = 2, kCfg1024x32x2 = 3
 
 // nineBit: the nine-bit hybrid plan is recorded in front of the passes, which are then only the fallback for skewed keys;
 // its status rows take half of the reference's partition-histogram area, so the passes must not take tiles of 16384.
-int ConfigIndex(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount, bool atomicRank, bool nineBit = false) {
+int ConfigIndex(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount, bool atomicRank, bool nineBit = false,
+                bool msd = false) {
   const int forced = ForcedConfigIndex();
   // (the two-sub-tile kernel is keys-only: a key+value sort under a forced 1024x32x2 takes 1024x32)
   if (forced >= 0) return forced == kCfg1024x32x2 && (keyValue || !atomicRank) ? kCfg1024x32 : forced;
@@ -116,6 +117,10 @@ int ConfigIndex(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount
     if (f > 1.0 && f <= 1.35 && !nineBit) return kCfg1024x16;
     return kCfg1024x32;
   }
+  // Behind the MSD plan the passes are the fallback only, and the plan's own launches double as its first two (one kernel, two
+  // roles): those fused kernels exist for the two-sub-tile geometry, which is then taken at every size (at one round of tiles
+  // and below as even-split tiles of two half-size sub-tiles).
+  if (msd && atomicRank) return kCfg1024x32x2;
   if (f <= 0.125) return kCfg1024x8;
   if (f <= 0.5) return kCfg1024x16;   // beyond: even-split 1024x32 tiles (PlanTiles), 7 % faster at f = 0.536
   if (f <= 1.0) return kCfg1024x32;
@@ -229,7 +234,12 @@ uint32_t Hybrid9Capacity(bool atomicRank, uint32_t elementCount, uint32_t hybrid
 // at these sizes): ten bits up to 36.6 M keys / 32.5 M pairs, eleven bits up to twice that.  Returns the bits or 0.
 // One-atomic ranking only.  VRDX_MSD=0 switches it off (VRDX_HYBRID=0 and a forced tile geometry as well); VRDX_MSD_FROM=n
 // records it from n elements up instead (measurements: below its default range it replaces the other two plans).
-uint32_t MsdTileKeys(uint32_t) { return vrdx::kMsdTileKeys; }
+// Keys per tile of the MSD plan's histogram and scatter: equal tiles that fill whole rounds of one workgroup per CU
+// (vrdx_layout.h).  VRDX_MSD_EVEN=0: tiles of full capacity (measurements).
+uint32_t MsdTileKeys(uint32_t elementCount, uint32_t cus) {
+  static const int even = TuningKnob("VRDX_MSD_EVEN");
+  return even == 0 ? vrdx::kMsdTileKeys : vrdx::MsdTileKeysFor(elementCount, cus, vrdx::kMsdMaxTiles);
+}
 
 uint32_t MsdBits(bool atomicRank, bool keyValue, uint32_t elementCount, uint32_t hybridCap, uint32_t* capacity) {
   static const bool enabled = [] {
@@ -367,7 +377,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   uint32_t cap9 = ForcedConfigIndex() < 0 && msdBits == 0
                       ? Hybrid9Capacity(atomicRank, elementCount, hybridCap, (uint32_t)sorter->computeUnits)
                       : 0u;
-  const int configIndex = ConfigIndex(sorter, keyValue, elementCount, atomicRank, cap9 != 0 || msdBits != 0);
+  const int configIndex = ConfigIndex(sorter, keyValue, elementCount, atomicRank, cap9 != 0 || msdBits != 0, msdBits != 0);
   vrdx::TilePlan tilePlan = PlanTiles(sorter, configIndex, keyValue, elementCount, atomicRank);
   // Block sums instead of the look-back chain: sorts of one round (PlanTiles) on the four-pass plan -- with a hybrid
   // plan recorded, launch 0 may rank by another byte than its pass index, which the block-sum form does not look up.
@@ -380,7 +390,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
                               ? (uint32_t)slots9Knob
                               : vrdx::Scatter9Slots(elementCount, (uint32_t)sorter->computeUnits);
   uint32_t tiles9 = cap9 != 0 ? vrdx::RoundUp(elementCount, slots9 * 1024u) : 0u;
-  const uint32_t msdTileKeys = MsdTileKeys(elementCount);
+  const uint32_t msdTileKeys = MsdTileKeys(elementCount, (uint32_t)sorter->computeUnits);
   const uint32_t msdTiles = vrdx::RoundUp(elementCount, msdTileKeys);
   vrdx::StorageLayout layout = vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, tilePlan.tiles,
                                                 (uint64_t)reinterpret_cast<uintptr_t>(storage), blockSums, tiles9, msdBits,
@@ -481,7 +491,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
       if (forcedGrid <= 0) grid = std::min<uint32_t>(msdTiles, cap);
       EnqueueCheck(sorter, "histogram_msd_kernel",
                    vrdx::LaunchHistogramMsd(stream, grid, keys, elementCount, countPtr, globalHistogram, tickets,
-                                            storage + layout.statusClearOffset, (uint32_t)layout.statusClearBytes,
+                                            storage + layout.statusClearOffset, 0u /* the spine kernel clears status region 0 */,
                                             reinterpret_cast<uint32_t*>(storage + layout.msdCountsOffset), msdTiles, msdBits,
                                             msdTileKeys));
     } else {
@@ -606,6 +616,8 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     m.cap = msdCap;
     m.tiles = msdTiles;
     m.tileKeys = msdTileKeys;
+    m.statusClear = storage + layout.statusClearOffset;
+    m.statusVecs = (uint32_t)(layout.statusClearBytes / 16u);
     // Timestamps: the plan's own three stages take the names they have in the reference -- slot 2 "upsweep" = the
     // histogram, 3 "spine", 4 "downsweep" = the scatter -- and the bucket sorts are pass 1's "upsweep" (slot 5, like the
     // eight-bit plan's); the four returning passes share the slots behind.

@@ -152,7 +152,7 @@ hipError_t LaunchBucketSort9(hipStream_t stream, bool keyValue, const BucketSort
 //                         11 bits inside its LDS, scratch -> caller.
 // All of it with wave-private counters of 16 bits, two to a word.  The device decides (the overflow word): with a bucket
 // beyond the capacity the last two return at once and the four passes recorded behind them run.
-constexpr uint32_t kMsdTileKeys = 32768;   // 1024 threads x 32 keys (16384 = x 16: two workgroups per CU)
+constexpr uint32_t kMsdTileKeys = 32768;   // a scatter tile's capacity: 1024 threads x 32 keys
 constexpr uint32_t kMsdMaxTiles = 2048;    // spine_msd_kernel: 64 chunks of at most 32 rows
 constexpr uint32_t kMsdCapKeys = 36864;    // bucket capacity, keys-only: 1024 threads x 36 keys (144 KiB of staging)
 constexpr uint32_t kMsdCapKeyValue = 36864;  // the same for pairs: keys and values take turns in the staging buffer
@@ -171,8 +171,12 @@ struct MsdArgs {
   uint32_t* planWord;          // VRDX_OFF_PLAN: the scatter writes 3 when the plan applies (the passes then return)
   uint32_t bits;               // 10 | 11
   uint32_t cap;                // elements a bucket may hold
-  uint32_t tiles;              // ceil(maxCount / tileKeys)
-  uint32_t tileKeys;           // 32768 | 16384
+  uint32_t tiles;              // ceil(maxCount / tileKeys) <= kMsdMaxTiles
+  uint32_t tileKeys;           // keys per tile of the histogram's counts and of the scatter: a multiple of 4096, at most kMsdTileKeys
+  // status region 0 of the fallback's passes (16-byte vectors): zeroed by the spine kernel, whose 32-64 workgroups have the
+  // bandwidth to spare, instead of by the histogram kernel (which it cost 1.9 us at 2^25, round 4)
+  void* statusClear;
+  uint32_t statusVecs;
 };
 hipError_t PrepareMsd();
 hipError_t LaunchHistogramMsd(hipStream_t stream, uint32_t grid, const uint32_t* keys, uint32_t maxCount,

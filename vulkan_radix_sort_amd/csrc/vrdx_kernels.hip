@@ -71,8 +71,14 @@ namespace vrdx {
 #ifndef VRDX_MSD_BUCKET_NT
 #define VRDX_MSD_BUCKET_NT 0
 #endif
+#ifndef VRDX_MSD_SCATTER_DYN
+#define VRDX_MSD_SCATTER_DYN 1
+#endif
+#ifndef VRDX_MSD_EVEN_WAVES
+#define VRDX_MSD_EVEN_WAVES 1  // bucket_sort2_kernel deals a bucket's chunks out evenly over its waves
+#endif
 #ifndef VRDX_MSD_OUT_NT
-#define VRDX_MSD_OUT_NT 0  // the bucket kernel's output stores non-temporal (measurement)
+#define VRDX_MSD_OUT_NT 1  // the bucket kernel's output stores non-temporal: 0 never, 1 by mode and size (the product), 2 always
 #endif
 
 
@@ -2210,15 +2216,17 @@ constexpr uint32_t kMsdTopBinWords = 8192;  // 32 KiB: 1024 bins x 8 replicas | 
 
 constexpr uint32_t HistMsdLdsBytes(uint32_t copies) { return (3u * 256u * copies + kMsdTopBinWords + 256u) * 4u; }
 
-template <uint32_t COPIES, uint32_t BITS, uint32_t GROUPS>
+template <uint32_t COPIES, uint32_t BITS>
 __global__ __launch_bounds__(kHistThreads) void histogram_msd_kernel(const uint32_t* __restrict__ keys, uint32_t maxCount,
                                                                       const uint32_t* countPtr,
                                                                       uint32_t* __restrict__ globalHistogram,
                                                                       uint32_t* __restrict__ tickets,
                                                                       u32x4* __restrict__ statusClear, uint32_t statusVecs,
-                                                                      uint32_t* __restrict__ tileCounts, uint32_t tiles) {
-  static_assert(kHistThreads == 1024 && (GROUPS == 1 || GROUPS == 2), "a tile is one or two groups of 16384 keys");
-  constexpr uint32_t kTileVecLog = GROUPS == 2 ? 13u : 12u;  // 16-byte vectors per tile
+                                                                      uint32_t* __restrict__ tileCounts, uint32_t tiles,
+                                                                      uint32_t rows) {
+  // rows: a tile is `rows` rows of 1024 sixteen-byte vectors = rows x 4096 keys (1 ... 8: the scatter's tiles of 4 ... 32 slots
+  // of 64 keys per wave, MsdTilePlan in vrdx_api.cpp)
+  static_assert(kHistThreads == 1024, "a row of vectors per load instruction");
   constexpr uint32_t D = 1u << BITS;
   constexpr uint32_t TC = kMsdTopBinWords / D;        // replicas of a top-bits bin
   constexpr uint32_t kByteWords = 3u * VRDX_RADIX * COPIES;
@@ -2247,10 +2255,21 @@ __global__ __launch_bounds__(kHistThreads) void histogram_msd_kernel(const uint3
     else if (lane == (uint32_t)__builtin_ctzll(active))
       atomicAdd(&top[t * TC], (uint32_t)__popcll(active));
   };
-  auto tally = [&](uint32_t group, const u32x4 (&k)[4], uint32_t nvec) {
+  // rows [first, first + 4) of tile `tile`: loads (index clamped, like HistFetch) and counts (masked by row and by nvec)
+  const uint32_t tileVecs = rows * kHistThreads;
+  auto fetch = [&](auto streaming, uint32_t tile, uint32_t first, uint32_t nvec, u32x4 (&k)[4]) {
+    constexpr bool NT = decltype(streaming)::value;
 #pragma unroll
     for (uint32_t u = 0; u < 4; ++u) {
-      if (group * kHistGroupVecs + u * kHistThreads + tid < nvec) {
+      uint32_t i = tile * tileVecs + (first + u) * kHistThreads + tid;
+      i = i < nvec ? i : (nvec != 0 ? nvec - 1 : 0u);
+      k[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(keys) + i) : reinterpret_cast<const u32x4*>(keys)[i];
+    }
+  };
+  auto tally = [&](uint32_t tile, uint32_t first, const u32x4 (&k)[4], uint32_t nvec) {
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      if (first + u < rows && tile * tileVecs + (first + u) * kHistThreads + tid < nvec) {
         count(k[u][0]);
         count(k[u][1]);
         count(k[u][2]);
@@ -2282,45 +2301,25 @@ __global__ __launch_bounds__(kHistThreads) void histogram_msd_kernel(const uint3
   };
 
   const uint32_t nvec = n >> 2;
-  const u32x4* keys4 = reinterpret_cast<const u32x4*>(keys);
   auto sweep = [&](auto streaming) {
-    constexpr bool NT = decltype(streaming)::value;
     const uint32_t step = gridDim.x;
     u32x4 a[4], b[4];
     uint32_t tile = blockIdx.x;
-    const auto tail = [&](uint32_t t) {  // the last one to three keys belong to the tile that holds key n - 1
-      if (t == (nvec >> kTileVecLog) && tid < (n & 3u)) count(keys[(nvec << 2) + tid]);
-    };
-    if constexpr (GROUPS == 2) {
-      HistFetch<NT>(keys4, 2 * tile, tid, nvec, a);
-      HistFetch<NT>(keys4, 2 * tile + 1, tid, nvec, b);
-    } else {
-      HistFetch<NT>(keys4, tile, tid, nvec, a);
-      HistFetch<NT>(keys4, tile + step, tid, nvec, b);
-    }
+    const bool two = rows > 4;  // (uniform) tiles of more than four rows keep a second set of loads in flight
+    fetch(streaming, tile, 0, nvec, a);
+    if (two) fetch(streaming, tile, 4, nvec, b);
     for (uint32_t i = tid; i < kByteWords + kMsdTopBinWords + 256u; i += kHistThreads) bins[i] = 0;
     LdsBarrier();
-    if constexpr (GROUPS == 2) {
-      for (; tile < tiles; tile += step) {
-        tally(2 * tile, a, nvec);
-        HistFetch<NT>(keys4, 2 * (tile + step), tid, nvec, a);
-        tally(2 * tile + 1, b, nvec);
-        HistFetch<NT>(keys4, 2 * (tile + step) + 1, tid, nvec, b);
-        tail(tile);
-        flush(tile);
+    for (; tile < tiles; tile += step) {
+      tally(tile, 0, a, nvec);
+      fetch(streaming, tile + step, 0, nvec, a);
+      if (two) {
+        tally(tile, 4, b, nvec);
+        fetch(streaming, tile + step, 4, nvec, b);
       }
-    } else {
-      for (; tile < tiles; tile += 2 * step) {
-        tally(tile, a, nvec);
-        HistFetch<NT>(keys4, tile + 2 * step, tid, nvec, a);
-        tail(tile);
-        flush(tile);
-        if (tile + step >= tiles) break;
-        tally(tile + step, b, nvec);
-        HistFetch<NT>(keys4, tile + 3 * step, tid, nvec, b);
-        tail(tile + step);
-        flush(tile + step);
-      }
+      // the last one to three keys belong to the tile that holds key n - 1
+      if (tile == nvec / tileVecs && tid < (n & 3u)) count(keys[(nvec << 2) + tid]);
+      flush(tile);
     }
   };
   const bool streamingInput = VRDX_HIST_NT == 2 || (VRDX_HIST_NT == 1 && n > kHistStreamingLoadsAbove);
@@ -2364,6 +2363,11 @@ __global__ __launch_bounds__(1024) void spine_msd_kernel(MsdArgs a) {
   const uint32_t r0 = c * rows;
   uint32_t* const column = a.tileCounts + w;
 
+  // status region 0 of the passes recorded behind the plan (nothing reads it before they start)
+  {
+    u32x4* const clear = reinterpret_cast<u32x4*>(a.statusClear);
+    for (uint32_t i = blockIdx.x * 1024u + tid; i < a.statusVecs; i += gridDim.x * 1024u) clear[i] = u32x4{0u, 0u, 0u, 0u};
+  }
   // keys below this workgroup's first bucket
   const uint32_t firstByte = (blockIdx.x * 2u * WORDS) >> (BITS - 8u);
   uint32_t under = tid < 256u && tid < firstByte ? a.histogramTable[3u * VRDX_RADIX + tid] : 0u;
@@ -2459,15 +2463,21 @@ __device__ __forceinline__ void ScatterMsdBody(const MsdArgs a) {
   // the grid is 8 C workgroups, C = ceil(tiles / 8): workgroup b takes tile (b % 8) C + b / 8 of its XCD's chunk
   const uint32_t perXcd = gridDim.x / 8u;
   const uint32_t tile = VRDX_MSD_XCD ? (blockIdx.x % 8u) * perXcd + blockIdx.x / 8u : blockIdx.x;
-  const uint32_t tileStart = tile * TILE;
+  // EVEN-SPLIT tiles (MsdTilePlan in vrdx_api.cpp): every wave takes `slots` of its KPT slots of 64 keys (a multiple of four),
+  // a tile is slots x 1024 keys, chosen so that the tiles fill whole rounds of one workgroup per CU -- 520 tiles of 32768 keys
+  // cost three rounds, the third for eight tiles; 768 tiles of 24576 cost three rounds of three quarters the length.
+  constexpr bool DYN = VRDX_MSD_SCATTER_DYN != 0;  // (0: tiles of full capacity only, with VRDX_MSD_EVEN=0 -- measurements)
+  const uint32_t slots = DYN ? a.tileKeys / (uint32_t)THREADS : (uint32_t)KPT;
+  const uint32_t frame = DYN ? a.tileKeys : TILE;
+  const uint32_t tileStart = tile * frame;
   // Verdict first, loads second: a wave cannot end with loads in flight, so a launch that is turned down (a bucket beyond the
   // capacity: the four passes behind it run) would still read every key -- 22 us at 2^25 for nothing, measured.
   if (*a.overflowWord != 0u) return;
-  const uint32_t valid = tile < a.tiles && tileStart < n ? ((n - tileStart) < TILE ? (n - tileStart) : TILE) : 0u;
+  const uint32_t valid = tile < a.tiles && tileStart < n ? ((n - tileStart) < frame ? (n - tileStart) : frame) : 0u;
   const uint32_t tileEnd = tileStart + valid;
-  const uint32_t loadBase = tileStart + wave * (KPT * 64) + lane;
+  const uint32_t loadBase = tileStart + wave * (slots * 64) + lane;
   uint32_t key[KPT];
-  LoadStriped<KPT, VRDX_MSD_NT_LOADS != 0>(a.keysCaller, loadBase, tileEnd, valid == TILE, 0xFFFFFFFFu, key);  // pad: downsweep.slang:81
+  LoadStriped<KPT, VRDX_MSD_NT_LOADS != 0, DYN>(a.keysCaller, loadBase, tileEnd, valid == frame, 0xFFFFFFFFu, key, slots);  // pad: downsweep.slang:81
   uint32_t prefixWord = 0, base0 = 0, base1 = 0;
   if ((uint32_t)tid < ROW && valid != 0) {
     prefixWord = a.tileCounts[(size_t)tile * ROW + tid];
@@ -2481,7 +2491,7 @@ __device__ __forceinline__ void ScatterMsdBody(const MsdArgs a) {
 #pragma unroll
   for (uint32_t i = 0; i < ROW / 256u; ++i) reinterpret_cast<u32x4*>(myRow)[lane + 64 * i] = u32x4{0u, 0u, 0u, 0u};
   uint32_t rank[KPT / 2];  // ranks, then physical staging slots, two to a register
-  RankPacked16<KPT, false>(key, SHIFT, MASK, myRow, lane, rank);
+  RankPacked16<KPT, DYN>(key, SHIFT, MASK, myRow, lane, rank, slots);
   ForgetDerivedValues<KPT>(key);
   LdsBarrier();
 
@@ -2497,14 +2507,18 @@ __device__ __forceinline__ void ScatterMsdBody(const MsdArgs a) {
     tileOffset[2 * tid + 1] = base1 + (prefixWord >> 16) - local1;
   }
   LdsBarrier();
-  PositionsPacked16<KPT, TILE, false>(key, SHIFT, MASK, myRow, rank);
+  PositionsPacked16<KPT, TILE, DYN>(key, SHIFT, MASK, myRow, rank, slots);
   LdsBarrier();  // the counters are dead: the staging buffer takes their place
 #pragma unroll
-  for (int i = 0; i < KPT; ++i) sorted[(rank[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = key[i];
+  for (int i = 0; i < KPT; ++i) {
+    if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
+    sorted[(rank[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = key[i];
+  }
   LdsBarrier();
   // key+value: the values are fetched now and land while the keys are scattered (like scatter9_kernel)
   uint32_t val[KV ? KPT : 1];
-  if constexpr (KV) LoadStriped<KPT, VRDX_MSD_NT_LOADS != 0>(a.valuesCaller, loadBase, tileEnd, valid == TILE, 0u, val);  // pad: downsweep.slang:85
+  if constexpr (KV)
+    LoadStriped<KPT, VRDX_MSD_NT_LOADS != 0, DYN>(a.valuesCaller, loadBase, tileEnd, valid == frame, 0u, val, slots);  // pad: downsweep.slang:85
 
   // scatter: whole single-digit quads in the main loop, the quads around a run's start by the thread that owns the run
   constexpr int QUADS = KPT / 4;
@@ -2566,7 +2580,10 @@ __device__ __forceinline__ void ScatterMsdBody(const MsdArgs a) {
   if constexpr (KV) {
     LdsBarrier();  // every key has left the staging buffer
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) sorted[(rank[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
+    for (int i = 0; i < KPT; ++i) {
+      if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
+      sorted[(rank[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
+    }
     LdsBarrier();
     scatterQuads(a.valuesScratch, false);
   }
@@ -2609,10 +2626,22 @@ __device__ __forceinline__ void BucketSort2Body(const MsdArgs a) {
   uint32_t* const valuesOut = KV ? a.valuesCaller + myBase : nullptr;
 
   constexpr bool DYN = true;
-  uint32_t slots = 4u * ((n + 4u * THREADS - 1u) / (4u * THREADS));
-  slots = slots < (uint32_t)KPT ? slots : (uint32_t)KPT;
-  const uint32_t first = wave * (slots * 64) + lane;  // element i of this lane: first + 64 * i
-  {
+  // The bucket's ceil(n / 256) chunks of four 64-element slots are dealt out EVENLY over the sixteen waves: wave w takes
+  // base + (w < extra) chunks, consecutive in memory (waves in order, (slot, lane) order inside a wave: the ranking stays
+  // stable).  With `slots` the same for every wave (SortInWorkgroup) a bucket of 16385 elements keeps thirteen waves busy
+  // with twenty slots each, and every phase lasts as long as twenty slots take; dealt out evenly one wave has twenty and
+  // fifteen have sixteen (VRDX_MSD_EVEN_WAVES = 0: the old rule, measurements).
+  uint32_t slots, first;
+  if (VRDX_MSD_EVEN_WAVES) {
+    const uint32_t chunks = (n + 255u) / 256u;  // <= 144: n <= 36864
+    const uint32_t base = chunks / WAVES, extra = chunks % WAVES;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
+    slots = 4u * (base + (w < extra ? 1u : 0u));
+    first = 256u * (w * base + (w < extra ? w : extra)) + lane;  // element i of this lane: first + 64 * i
+  } else {
+    slots = 4u * ((n + 4u * THREADS - 1u) / (4u * THREADS));
+    slots = slots < (uint32_t)KPT ? slots : (uint32_t)KPT;
+    first = wave * (slots * 64) + lane;
     // a wave whose range starts at or behind n holds nothing but pads and skips every loop over its slots (SortInWorkgroup)
     const uint32_t waveStart = (uint32_t)wave * (slots * 64);
     const uint32_t mine = n > waveStart ? n - waveStart : 0u;
@@ -2679,15 +2708,32 @@ __device__ __forceinline__ void BucketSort2Body(const MsdArgs a) {
     }
     LdsBarrier();  // the next pass clears its counters where the staging buffer is
   }
+  // Key+value sorts of more than 2^24 pairs write their result with NON-TEMPORAL stores: 256 MiB and more of output is the
+  // size of the Infinity Cache, and left dirty in the caches it is written back under the next kernel's reads -- the next
+  // sort's histogram in a batch of sorts.  Measured (tools/r05/out_nt2.sh, bench.py's loop of 20 sorts): key+value 82 ->
+  // 86.3 GItems/s at 2^25, a single sort on its own unchanged (0.4225 / 0.4239 ms).  Keys-only sorts keep plain stores:
+  // their loop gains the same 4 % but a single sort LOSES 4 % (its last kernel then waits for its own write-back), and a
+  // consumer of 128 MiB of sorted keys finds a good part of them in the cache.  (The empty asm statements keep the two
+  // kinds of store apart, see LoadTile.)
+  const bool streamOut = VRDX_MSD_OUT_NT == 2 || (VRDX_MSD_OUT_NT == 1 && KV && a.maxCount > kStreamingLoadsAbove);
+  if (streamOut) {
+    asm volatile("; non-temporal output" ::: "memory");
 #pragma unroll
-  for (int i = 0; i < KPT; ++i) {
-    if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
-    const uint32_t index = first + 64 * i;
-    if (index < n) {
-      if (VRDX_MSD_OUT_NT) {
+    for (int i = 0; i < KPT; ++i) {
+      if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
+      const uint32_t index = first + 64 * i;
+      if (index < n) {
         __builtin_nontemporal_store(key[i], &keysOut[index]);
         if constexpr (KV) __builtin_nontemporal_store(val[i], &valuesOut[index]);
-      } else {
+      }
+    }
+    asm volatile("" ::: "memory");
+  } else {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      if (DYN && i % 4 == 0 && (uint32_t)i >= slots) break;
+      const uint32_t index = first + 64 * i;
+      if (index < n) {
         keysOut[index] = key[i];
         if constexpr (KV) valuesOut[index] = val[i];
       }
@@ -3187,8 +3233,8 @@ static hipError_t PrepareMsdBits() {
     const void* fn;
     size_t bytes;
   } kernels[] = {
-      {reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, BITS, 2>), HistMsdLdsBytes(kHistCopies)},
-      {reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, BITS, 2>), HistMsdLdsBytes(kHistCopiesLarge)},
+      {reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, BITS>), HistMsdLdsBytes(kHistCopies)},
+      {reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, BITS>), HistMsdLdsBytes(kHistCopiesLarge)},
       {reinterpret_cast<const void*>(&scatter_msd_kernel<BITS, false>), ScatterMsdLdsWords<BITS>() * 4},
       {reinterpret_cast<const void*>(&scatter_msd_kernel<BITS, true>), ScatterMsdLdsWords<BITS>() * 4},
       {reinterpret_cast<const void*>(&bucket_sort2_kernel<BITS, kMsdCapKeys / 1024, false>), BucketSort2LdsWords<kMsdCapKeys / 1024>() * 4},
@@ -3230,19 +3276,19 @@ hipError_t LaunchHistogramMsd(hipStream_t stream, uint32_t grid, const uint32_t*
   const uint32_t vecs = statusClearBytes / 16u;
   const bool many = maxCount >= kHistManyCopiesFrom;
   const void* kernel;
-  // (tiles of 16384 keys -- two scatter workgroups per CU, the GROUPS = 1 form of the histogram -- were built and measured
-  // in round 5: scatter 97.6 instead of 93.3 us keys-only at 2^25, histogram 41 instead of 37; not instantiated)
-  if (tileKeys != kMsdTileKeys) return hipErrorInvalidValue;
+  // tiles of rows x 4096 keys (the scatter's even-split tiles); a tile of full capacity is eight rows
+  if (tileKeys == 0 || tileKeys % 4096u != 0 || tileKeys > kMsdTileKeys) return hipErrorInvalidValue;
+  const uint32_t rows = tileKeys / 4096u;
   if (bits == 10)
-    kernel = many ? reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, 10, 2>)
-                  : reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, 10, 2>);
+    kernel = many ? reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, 10>)
+                  : reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, 10>);
   else if (bits == 11)
-    kernel = many ? reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, 11, 2>)
-                  : reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, 11, 2>);
+    kernel = many ? reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, 11>)
+                  : reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, 11>);
   else
     return hipErrorInvalidValue;
   return Launch(kernel, grid, kHistThreads, HistMsdLdsBytes(many ? kHistCopiesLarge : kHistCopies), stream, keys, maxCount,
-                countPtr, globalHistogram, tickets, clear, vecs, tileCounts, tiles);
+                countPtr, globalHistogram, tickets, clear, vecs, tileCounts, tiles, rows);
 }
 
 hipError_t LaunchSpineMsd(hipStream_t stream, const MsdArgs& args) {
@@ -3255,7 +3301,7 @@ hipError_t LaunchSpineMsd(hipStream_t stream, const MsdArgs& args) {
 hipError_t LaunchScatterMsd(hipStream_t stream, bool keyValue, const MsdArgs& args) {
   const void* kernel;
   size_t lds;
-  if (args.tileKeys != kMsdTileKeys) return hipErrorInvalidValue;
+  if (args.tileKeys == 0 || args.tileKeys % 4096u != 0 || args.tileKeys > kMsdTileKeys) return hipErrorInvalidValue;
   if (args.bits == 10) {
     kernel = keyValue ? reinterpret_cast<const void*>(&scatter_msd_kernel<10, true>)
                       : reinterpret_cast<const void*>(&scatter_msd_kernel<10, false>);
@@ -3303,7 +3349,8 @@ static hipError_t LaunchMsdFusedBits(hipStream_t stream, bool bucketLaunch, cons
 
 hipError_t LaunchMsdFused(hipStream_t stream, bool bucketLaunch, bool keyValue, const MsdArgs& m, const OnesweepArgs& p,
                           uint32_t passGrid) {
-  if (keyValue || m.tileKeys != kMsdTileKeys || m.cap != kMsdCapKeys) return hipErrorInvalidValue;  // keys-only sorts only
+  if (keyValue || m.tileKeys == 0 || m.tileKeys % 4096u != 0 || m.tileKeys > kMsdTileKeys || m.cap != kMsdCapKeys)
+    return hipErrorInvalidValue;  // keys-only sorts only
   if (m.bits == 10) return LaunchMsdFusedBits<10, false>(stream, bucketLaunch, m, p, passGrid);
   if (m.bits == 11) return LaunchMsdFusedBits<11, false>(stream, bucketLaunch, m, p, passGrid);
   return hipErrorInvalidValue;

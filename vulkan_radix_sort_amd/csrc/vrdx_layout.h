@@ -174,6 +174,18 @@ static inline uint32_t Scatter9Slots(uint32_t elementCount, uint32_t cus) {
   return slots > 32u ? 32u : slots;
 }
 
+// The MSD plan's scatter (scatter_msd_kernel, one workgroup per CU and tile) cuts the sort into EQUAL tiles that fill whole
+// rounds of `cus` tiles: keys per tile, a multiple of 4096 (four 64-key slots per wave of its 1024 threads), at most 32768.
+// 520 tiles of 32768 keys would cost three rounds, the third for eight tiles; 768 tiles of 24576 cost three rounds of three
+// quarters the length.  maxTiles: the spine kernel's reach; beyond it, tiles of full capacity.
+static inline uint32_t MsdTileKeysFor(uint32_t elementCount, uint32_t cus, uint32_t maxTiles) {
+  if (elementCount == 0 || cus == 0) return 32768u;
+  const uint32_t rounds = RoundUp(elementCount, cus * 32768u);
+  uint32_t keys = 4096u * RoundUp(RoundUp(elementCount, rounds * cus), 4096u);
+  if (keys > 32768u) keys = 32768u;
+  return RoundUp(elementCount, keys) <= maxTiles ? keys : 32768u;
+}
+
 // Tile plan.  The 1024x32 kernels hold one workgroup per CU, so a sort of T full tiles takes ceil(T / CUs) rounds
 // however full the last round is: 257 tiles cost two rounds, and so do 512.  Two remedies, both through the kernels'
 // run-time slot counts (OnesweepArgs::slots / fullTiles / tailSlots, SpanOfTile in vrdx_kernels.hip):
