@@ -509,7 +509,7 @@ def main():
         plan = sorter.describe_plan(n, key_value)
         item = 8.0 if key_value else 4.0   # bytes of one element (key [+ value]) in one direction
         if plan.name == "msd":
-            names = {"histogram": "histogram_msd_kernel<32u, %du, 2u>" % plan.bits,
+            names = {"histogram": "histogram_msd_kernel<32u, %du>" % plan.bits,
                      "spine": "spine_msd_kernel<%du>" % plan.bits,
                      # keys-only: the plan's scatter / bucket launches are also pass 0 / pass 1 of the fallback (one kernel,
                      # two roles chosen on the device); two passes remain as launches that return on the verdict

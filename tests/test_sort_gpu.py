@@ -908,12 +908,24 @@ def test_maximum_size_2pow30_minus_4_properties(torch_mod, sorter):
     sorter.cmd_sort(stream, n, keys.data_ptr(), 0, storage.data_ptr(), 0)
     torch.cuda.synchronize()
     assert sorter.read_status(stream, storage.data_ptr(), 0) == 0
-    del storage
     assert checksums(keys) == before
     for lo in range(0, n, chunk):
         hi = min(n, lo + chunk + 1)          # overlap by one element: boundaries are checked too
         u = keys[lo:hi].to(torch.int64) & 0xFFFFFFFF
         assert bool((u[1:] >= u[:-1]).all()), lo
+    # A count BEYOND 2^30 - 4 is clamped to it -- and says so (VRDX_HIP_STATUS_COUNT_CLAMPED, bit 30 of the sorter's word;
+    # the reference's uint32 size math wraps there, src/vk_radix_sort.h.in:105-115): indirect with a small device-side
+    # count, so that only the bound is out of range and the (already sorted) prefix is what gets sorted.
+    import vulkan_radix_sort_amd as vrdx
+    assert sorter.read_sorter_status(stream) == 0
+    count = torch.tensor([100003, 0, 0, 0], dtype=torch.int32, device="cuda")
+    head_before = keys[:100003].clone()
+    sorter.cmd_sort_indirect(stream, (1 << 30) + 12345, count.data_ptr(), 0, keys.data_ptr(), 0, storage.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert sorter.read_sorter_status(stream) == vrdx.STATUS_COUNT_CLAMPED
+    assert sorter.read_sorter_status(stream) == 0                      # reading clears it
+    assert bool((keys[:100003] == head_before).all())                  # sorted input stays as it is
+    del storage
 
 
 def test_native_selftest_binary(torch_mod):

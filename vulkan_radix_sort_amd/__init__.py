@@ -19,6 +19,12 @@ from .api import (  # noqa: F401
     EXPORTED_SYMBOLS,
     version_string,
     event_overhead_ns,
+    VrdxHipPlanInfo,
+    PLAN_NAMES,
+    STATUS_LOOKBACK_GAVE_UP,
+    STATUS_RANK_ORDER,
+    STATUS_COUNT_CLAMPED,
+    STATUS_ENQUEUE_REFUSED,
 )
 
 __all__ = [
@@ -32,4 +38,10 @@ __all__ = [
     "EXPORTED_SYMBOLS",
     "version_string",
     "event_overhead_ns",
+    "VrdxHipPlanInfo",
+    "PLAN_NAMES",
+    "STATUS_LOOKBACK_GAVE_UP",
+    "STATUS_RANK_ORDER",
+    "STATUS_COUNT_CLAMPED",
+    "STATUS_ENQUEUE_REFUSED",
 ]

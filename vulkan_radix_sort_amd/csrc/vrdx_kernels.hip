@@ -1823,21 +1823,20 @@ __device__ __forceinline__ void SortInWorkgroup(const uint32_t* keysIn, uint32_t
   uint32_t* const myHist = waveHist + wave * 256;
   constexpr bool DYN = KPT >= 8;
   uint32_t slots = KPT;
+  uint32_t first = wave * (KPT * 64) + lane;  // element i of this lane: first + 64 * i
+  // The ceil(n / 256) chunks of four 64-element slots are dealt out EVENLY over the waves (round 5): wave w takes
+  // base + (w < extra) chunks, consecutive in memory -- waves in order, (slot, lane) order inside a wave, so the ranking stays
+  // stable; pads (the largest key, last in memory order) only ever sit in the last chunk.  Round 4 gave every wave the same
+  // `slots` and let the waves behind n idle: the LDS work followed the bucket's size in steps of 256 elements
+  // (profiles/r04_bucket_granule.txt), but a bucket of 16385 elements kept thirteen waves busy with twenty slots each and
+  // every phase lasted as long as twenty slots take -- the 7-10 % steps of the size curve wherever the mean bucket crossed a
+  // multiple of 4096 (4.2 / 4.5 / 6.0 / 6.3 M elements).  Dealt out evenly, one wave has twenty and the others sixteen.
   if constexpr (DYN) {
-    slots = 4u * ((n + 4u * THREADS - 1u) / (4u * THREADS));
-    slots = slots < (uint32_t)KPT ? slots : (uint32_t)KPT;
-  }
-  const uint32_t first = wave * (slots * 64) + lane;  // element i of this lane: first + 64 * i
-  // A wave whose range starts at or behind n holds nothing but pads, before the sort and after every pass of it (pads
-  // carry the largest key and sit last in memory order): it skips every loop over its slots, and the wave that n cuts
-  // through walks only the chunks of four slots it has elements in.  The layout (first) stays that of `slots` slots per
-  // wave.  So the LDS work of a bucket follows its size in steps of 256 elements, not of 4096: without this a bucket of
-  // 16385 elements cost what 20480 cost (profiles/r04_bucket_granule.txt).
-  if constexpr (DYN) {
-    const uint32_t waveStart = (uint32_t)wave * (slots * 64);
-    const uint32_t mine = n > waveStart ? n - waveStart : 0u;
-    const uint32_t waveSlots = 4u * ((mine + 255u) / 256u);
-    slots = waveSlots < slots ? waveSlots : slots;
+    const uint32_t chunks = (n + 255u) / 256u;  // <= WAVES * KPT / 4
+    const uint32_t base = chunks / WAVES, extra = chunks % WAVES;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
+    slots = 4u * (base + (w < extra ? 1u : 0u));
+    first = 256u * (w * base + (w < extra ? w : extra)) + lane;
   }
 
   uint32_t key[KPT];
