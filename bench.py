@@ -458,6 +458,9 @@ def main():
             print(f"[bench] --gpus {args.gpus} but {n_gpus} rank(s) are running: refusing to report", file=sys.stderr)
         sys.exit(2)
 
+    import resource
+    torch.zeros(1, device=device)   # the runtime is up: what the process weighs before it holds a single input
+    rss_runtime_mib = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0
     n = 1 << args.log2n
     executor = HipShardExecutor(local_rank)   # one VrdxSorter + stream + storage for this GPU
     sorter = executor.sorter
@@ -474,6 +477,7 @@ def main():
     pristine = upload_streams(torch, n, list(range(seed0, seed0 + total + (CURVE_STREAMS if extras else 2))), device)
     setup_s = time.perf_counter() - t_setup
     to_first_region_s = time.perf_counter() - t_process   # start of main() -> inputs resident, first barrier next
+    rss_inputs_mib = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0
     fresh = (pristine[0][total:], pristine[1][total:])   # never sorted in place
     wall_keys, steps_keys = timed_sorts(torch, dist, executor, pristine, n, args.steps, args.warmup, False, device, distributed)
     wall_kv, steps_kv = timed_sorts(torch, dist, executor, pristine, n, args.steps, args.warmup, True, device, distributed)
@@ -603,7 +607,8 @@ def main():
                     "note": "north-star floor from the reference README (other hardware), not a vs_baseline"},
         "roofline": roofline,
         "setup": {"input_generation_and_upload_s": setup_s, "seconds_to_first_timed_region": to_first_region_s,
-                  "streams": len(pristine[0]), "host_streams_in_flight": GENERATOR_THREADS},
+                  "streams": len(pristine[0]), "host_streams_in_flight": GENERATOR_THREADS,
+                  "rss_mib_runtime_up": rss_runtime_mib, "rss_mib_inputs_resident": rss_inputs_mib},
     }
     if extras and not args.no_sweep:
         t_curve = time.perf_counter()
@@ -616,8 +621,7 @@ def main():
     del pristine, fresh
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(n)
-    import resource
-    result["setup"]["peak_rss_mib"] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0   # (Linux: KiB)
+    result["setup"]["peak_rss_mib"] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0   # (Linux: KiB; incl. the cpu_baseline leg)
     if rank == 0:
         print(json.dumps(result))
     executor.close()

@@ -707,7 +707,12 @@ def test_two_valued_bytes_take_the_ballot_ranking(torch_mod, sorter, oracle, n):
     dense_sorted = (np.arange(n, dtype=np.uint64) // 3).astype(np.uint32)          # every key three times, ascending
     i = np.arange(n, dtype=np.uint64)
     mixed = (((i & 1) * 0xFF) << 24) | ((i % 4099 == 0) * np.uint64(0x7F0000)) | (rng.integers(0, 1 << 16, size=n, dtype=np.uint64))
-    for k in (small_signed, dense_sorted, mixed.astype(np.uint32)):
+    # slots of three and four digit values (round 5 tried a ballot form for up to four groups and did not adopt it: they
+    # take the returning atomic, 16- to 32-way on as many counters -- correct, only slower): four distinct keys, and a byte of
+    # three values under random low bits
+    four = np.array([3, 0xFFFFFFFF, 0x00010000, 0x7F000000], np.uint32)[rng.integers(0, 4, n)]
+    three = (np.array([0x11, 0x80, 0xFE], np.uint32)[rng.integers(0, 3, n)] << np.uint32(16)) | rng.integers(0, 1 << 8, size=n, dtype=np.uint64).astype(np.uint32)
+    for k in (small_signed, dense_sorted, mixed.astype(np.uint32), four, three):
         ek, ep, _ = oracle.sort(k, iota)
         gk, _ = gpu_sort(torch_mod, sorter, k)
         assert np.array_equal(gk, ek)
