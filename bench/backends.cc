@@ -72,6 +72,15 @@ class HipBenchmark : public BenchmarkBase {
     if (vrdxHipCreateQueryPool(15, &pool_) != VK_SUCCESS) std::exit(2);
     BENCH_HIP_OK(hipEventCreate(&start_));
     BENCH_HIP_OK(hipEventCreate(&end_));
+    // VRDX_BENCH_RESERVE=<elements>: allocate for that many pairs up front instead of growing with the sweep (the reference
+    // grows, bench/vulkan_benchmark.cc:225-250, but from VMA's 256 MiB blocks; hipMalloc hands out fresh pages at every
+    // size, and what mapping a size gets shows in its ten sorts -- tools/r05/jitter.sh).
+    if (const char* reserve = std::getenv("VRDX_BENCH_RESERVE")) {
+      const uint32_t n = static_cast<uint32_t>(std::strtoul(reserve, nullptr, 10));
+      VrdxSorterStorageRequirements req;
+      vrdxGetSorterKeyValueStorageRequirements(sorter_, n, &req);
+      Reserve(size_t(2) * Align(n * 4u) + 16, req.size);
+    }
   }
   ~HipBenchmark() override {
     (void)hipStreamSynchronize(stream_);

@@ -495,6 +495,43 @@ void Bench(Harness& h, const std::vector<int>& logs) {
 }
 
 
+// Every sample of the reference protocol at one size, not just the median: `rounds` times 1 warm-up + 10 sorts of fresh
+// mt19937 data with the 15-slot timestamp contract, one line per sort (total and the stage intervals).  For telling a slow
+// median apart: a slow size (every sample), a slow process (every sample of one round) or scattered slow sorts.
+void Jitter(Harness& h, uint32_t n, bool kv, int rounds) {
+  VrdxSorterStorageRequirements req;
+  if (kv)
+    vrdxGetSorterKeyValueStorageRequirements(h.sorter, n, &req);
+  else
+    vrdxGetSorterStorageRequirements(h.sorter, n, &req);
+  const uint32_t inout = Align16(n * 4u);
+  h.reserve((size_t)2 * inout + 16, (size_t)req.size + StorageOffset());
+  VrdxHipPlanInfo plan;
+  vrdxHipDescribePlan(h.sorter, n, kv, &plan);
+  std::printf("# n=%u %s plan=%u bits=%u keys@%p storage@%p\n", n, kv ? "kv" : "keys", plan.plan, plan.bits, (void*)h.dKeys, (void*)h.dStorage);
+  for (int round = 0; round < rounds; ++round)
+    for (int runIdx = 0; runIdx < 11; ++runIdx) {
+      std::vector<uint32_t> v;
+      auto k = Mt(n, runIdx + 1, 32, &v);
+      HIP_OK(hipMemcpy(h.dKeys, k.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+      HIP_OK(hipMemcpy(h.dKeys + inout, v.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+      HIP_OK(hipDeviceSynchronize());
+      if (kv)
+        vrdxCmdSortKeyValue((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dKeys, inout,
+                            (VkBuffer)h.dStorage, StorageOffset(), h.pool, 0);
+      else
+        vrdxCmdSort((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dStorage, StorageOffset(), h.pool, 0);
+      HIP_OK(hipStreamSynchronize(h.stream));
+      uint64_t ts[15];
+      if (vrdxHipGetQueryPoolResults(h.pool, 0, 15, ts) != VK_SUCCESS) std::exit(3);
+      std::printf("%u %s round %d run %2d total %7.1f us | fill %5.1f hist %5.1f |", n, kv ? "kv" : "keys", round, runIdx, ts[14] / 1e3,
+                  (ts[1] - ts[0]) / 1e3, (ts[2] - ts[1]) / 1e3);
+      for (int i = 3; i < 15; ++i) std::printf(" %5.1f", (ts[i] - ts[i - 1]) / 1e3);
+      std::printf("\n");
+    }
+  std::fflush(stdout);
+}
+
 // Timing-only size sweep for tile-geometry break points: N = 2^(lo + i*(hi-lo)/(points-1)), one
 // random key/value set generated once (each run re-uploads the first N), median of 7 event-bracketed
 // sorts without a query pool.
@@ -818,6 +855,11 @@ int main(int argc, char** argv) {
   if (what == "soak")  // soak [seconds] [max elements]
     return Soak(h, argc > 2 ? std::atoi(argv[2]) : 30, argc > 3 ? (uint32_t)std::strtoul(argv[3], nullptr, 10) : 3u << 20) ? 1 : 0;
   if (what == "adversarial") return Adversarial(h, argc > 2 ? std::atoi(argv[2]) : 25) ? 1 : 0;
+  if (what == "jitter") {  // jitter <n> [keys|kv] [rounds]
+    Jitter(h, argc > 2 ? (uint32_t)std::strtoul(argv[2], nullptr, 10) : 1572864u, argc > 3 && std::string(argv[3]) == "kv",
+           argc > 4 ? std::atoi(argv[4]) : 3);
+    return 0;
+  }
   if (what == "bench") {
     std::vector<int> logs;
     for (int i = 2; i < argc; ++i) logs.push_back(std::atoi(argv[i]));

@@ -52,6 +52,7 @@ def expected_kernels():
                                  % (threads, kpt, kv, atomic, even))
     # the MSD plan: histogram with per-tile counts, spine, scatter, two-pass bucket sort; the packed-counter order check
     names.append("_ZN4vrdx29lds_order_check_packed_kernelEPjS0_")
+    names += ["_ZN4vrdx24bucket_sort2_half_kernelILj10ELb%dEEEvNS_7MsdArgsE" % kv for kv in (0, 1)]
     for bits in (10, 11):
         names.append("_ZN4vrdx16spine_msd_kernelILj%dEEEvNS_7MsdArgsE" % bits)
         names += ["_ZN4vrdx20histogram_msd_kernelILj%dELj%dEEEvPKjjS2_PjS3_PDv4_jjS3_jj" % (c, bits) for c in (8, 32)]

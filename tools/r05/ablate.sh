@@ -23,7 +23,7 @@ for v in "$@"; do
 import csv, sys, re
 for r in csv.DictReader(open(sys.argv[1])):
     name = re.sub(r'\(.*', '', r['Name']).replace('void vrdx::', '')
-    if 'msd' in name or 'sort2' in name:
+    if 'msd' in name or 'sort2' in name or 'histogram' in name:
         print(f"{name:55s} calls {r['Calls']:>4s} avg_us {float(r['AverageNs'])/1e3:8.1f} min {float(r['MinNs'])/1e3:8.1f} max {float(r['MaxNs'])/1e3:8.1f}")
 PY
 done

@@ -251,18 +251,24 @@ uint32_t MsdBits(bool atomicRank, bool keyValue, uint32_t elementCount, uint32_t
   static const int forcedBits = TuningKnob("VRDX_MSD_BITS");  // measurements: 10 | 11 wherever the capacity allows
   static const int knobLast = TuningKnob("VRDX_HYBRID_HEADROOM_LAST");
   if (!enabled || !atomicRank) return 0;
-  // Key+value: from where the nine-bit plan ends (16.2 M: below, that plan is 3-6 % faster for pairs).  Keys-only: from
-  // where the EIGHT-bit plan ends (8.1 M: hybridCap == 0) -- with two of its fallback's launches folded into its own it is
-  // 6 % faster than the four passes at one round of tiles, within 2 % of the nine-bit plan up to 11.5 M and 1-4 % faster
-  // from there on (profiles/r05_msd_threshold_sweep.txt), so keys-only sorts no longer record the nine-bit plan at all.
-  const uint32_t lowest = from > 0 ? (uint32_t)from : (keyValue ? 16252929u : (hybridCap == 0 ? vrdx::kSmallSortMaxElements + 1u : ~0u));
+  // From where the EIGHT-bit plan ends (8.1 M: hybridCap == 0), keys-only and key+value.  Up to 16.2 M elements the buckets
+  // hold at most 16384 and the half-size bucket kernel sorts them, two workgroups to a CU: with it the plan is 8-15 % faster
+  // than the nine-bit plan and the four passes at one round of tiles, which key+value sorts of these sizes took before
+  // (profiles/r05_msd_half_buckets.txt); the nine-bit plan is recorded only with VRDX_MSD=0.
+  const uint32_t lowest = from > 0 ? (uint32_t)from : (hybridCap == 0 ? vrdx::kSmallSortMaxElements + 1u : ~0u);
   if (elementCount < lowest || vrdx::RoundUp(elementCount, vrdx::kMsdTileKeys) > vrdx::kMsdMaxTiles) return 0;
   const uint32_t cap = keyValue ? vrdx::kMsdCapKeyValue : vrdx::kMsdCapKeys;
   *capacity = cap;
   for (uint32_t bits = 10; bits <= 11; ++bits) {
     if (forcedBits > 0 && (uint32_t)forcedBits != bits) continue;
     const uint64_t mean = ((uint64_t)elementCount + (1u << bits) - 1u) >> bits;
-    if (mean * (uint64_t)(knobLast > 0 ? knobLast : 103) / 100u <= cap) return bits;
+    if (mean * (uint64_t)(knobLast > 0 ? knobLast : 103) / 100u <= cap) {
+      // buckets of half the size: the bucket kernel of 512 threads, two workgroups per CU (bucket_sort2_half_kernel)
+      static const int half = TuningKnob("VRDX_MSD_HALF");
+      if (bits == 10 && half != 0 && mean * (uint64_t)(knobLast > 0 ? knobLast : 103) / 100u <= vrdx::kMsdHalfCap)
+        *capacity = vrdx::kMsdHalfCap;
+      return bits;
+    }
   }
   return 0;
 }
@@ -594,7 +600,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
 #endif
     return args;
   };
-  bool msdFused = false;
+  uint32_t msdFused = 0;  // how many of the plan's launches double as the fallback's first passes (0 | 1: the scatter | 2: and the buckets)
   // The MSD plan, recorded in front of the passes like the nine-bit plan: spine (prefixes over the tiles, bucket table,
   // verdict), scatter by the top bits, one workgroup per bucket.  The passes behind return on the verdict word.
   if (msdBits != 0) {
@@ -628,21 +634,21 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     // device): only passes 2 and 3 remain as launches that return when the plan runs.  The fused kernels exist for the
     // geometry the recorder selects at these sizes (ConfigIndex: the two-sub-tile kernel).
     // Keys-only sorts (the key+value form measured slower than the launches it saves, vrdx_kernels.hip).
-    msdFused = !keyValue && configIndex == kCfg1024x32x2 && TuningKnob("VRDX_MSD_FUSED") != 0;
-    if (msdFused) {
+    // Buckets of the half-size kernel (512 threads; the passes' bodies need 1024): only the scatter launch has a second role.
+    msdFused = !keyValue && configIndex == kCfg1024x32x2 && TuningKnob("VRDX_MSD_FUSED") != 0 ? (msdCap == vrdx::kMsdCapKeys ? 2u : 1u) : 0u;
+    if (msdFused >= 1)
       EnqueueCheck(sorter, "msd_scatter_or_pass0_kernel", vrdx::LaunchMsdFused(stream, false, keyValue, m, passArgs(0), tilePlan.tiles));
-      Stamp(pool, query + 4, stream);
-      EnqueueCheck(sorter, "msd_buckets_or_pass1_kernel", vrdx::LaunchMsdFused(stream, true, keyValue, m, passArgs(1), tilePlan.tiles));
-      Stamp(pool, query + 5, stream);
-    } else {
+    else
       EnqueueCheck(sorter, "scatter_msd_kernel", vrdx::LaunchScatterMsd(stream, keyValue, m));
-      Stamp(pool, query + 4, stream);
+    Stamp(pool, query + 4, stream);
+    if (msdFused >= 2)
+      EnqueueCheck(sorter, "msd_buckets_or_pass1_kernel", vrdx::LaunchMsdFused(stream, true, keyValue, m, passArgs(1), tilePlan.tiles));
+    else
       EnqueueCheck(sorter, "bucket_sort2_kernel", vrdx::LaunchBucketSort2(stream, keyValue, m));
-      Stamp(pool, query + 5, stream);
-    }
+    Stamp(pool, query + 5, stream);
   }
   for (uint32_t pass = 0; pass < VRDX_PASSES; ++pass) {
-    if (msdFused && pass < 2) {  // these two ran (or returned) inside the plan's own launches
+    if (pass < msdFused) {  // ran (or returned) inside the plan's own launches
       if (pass == 1) {
         StampSame(pool, query + 6, query + 5);
         StampSame(pool, query + 7, query + 5);
@@ -1031,7 +1037,9 @@ void vrdxHipDescribePlan(VrdxSorter sorter, uint32_t elementCount, int keyValue,
     info->plan = VRDX_HIP_PLAN_MSD;
     info->bits = msdBits;
     info->bytesPerElement = twoTrips;
-    info->launches = kv ? 8u : 6u;  // histogram, spine, scatter, buckets, four returning passes (keys-only: two of them folded into the plan's launches)
+    // histogram, spine, scatter, buckets, four returning passes (keys-only: two of them folded into the plan's launches,
+    // one with the half-size bucket kernel)
+    info->launches = kv ? 8u : (msdCap == vrdx::kMsdCapKeys ? 6u : 7u);
   } else if (cap9 != 0) {
     info->plan = VRDX_HIP_PLAN_HYBRID9;
     info->bits = 9;

@@ -100,6 +100,7 @@ namespace vrdx {
 // ---------------------------------------------------------------------------------------------
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef u32x4 u32x4_a4 __attribute__((aligned(4)));  // 16-byte access, 4-byte aligned
 
 // Tile status words cross CUs and XCDs inside one launch: every access is a relaxed agent-scope
@@ -2175,6 +2176,30 @@ __device__ __forceinline__ void ColumnBasesFrom(uint32_t* counters, uint32_t col
   }
 }
 
+// The same with TWO words (four digits) per thread, for workgroups of half as many threads as a row has words: thread
+// `col` owns words 2 col and 2 col + 1 of every wave's row and reads them as one 8-byte quantity (a stride of two words
+// in 4-byte reads would conflict two ways).  ColumnPairRead returns the totals of the two words; ColumnPairBasesFrom
+// writes the bases, `add` holding the four digits' starting positions (lo | hi << 16 per word).
+template <uint32_t ROW, int WAVES>
+__device__ __forceinline__ u32x2 ColumnPairRead(const uint32_t* counters, uint32_t col, u32x2 (&column)[WAVES]) {
+  u32x2 total = {0u, 0u};
+#pragma unroll
+  for (int w = 0; w < WAVES; ++w) {
+    column[w] = reinterpret_cast<const u32x2*>(counters + w * ROW)[col];
+    total += column[w];
+  }
+  return total;
+}
+template <uint32_t ROW, int WAVES>
+__device__ __forceinline__ void ColumnPairBasesFrom(uint32_t* counters, uint32_t col, u32x2 add, const u32x2 (&column)[WAVES]) {
+  u32x2 running = add;
+#pragma unroll
+  for (int w = 0; w < WAVES; ++w) {
+    reinterpret_cast<u32x2*>(counters + w * ROW)[col] = running;
+    running += column[w];
+  }
+}
+
 // ranks -> physical staging slots, in place: slot = StagingSlot(row[digit] + rank).  Reads only; the staging buffer may
 // alias the counters once every wave has been through here (the caller's barrier).
 template <int KPT, uint32_t STAGE, bool DYN>
@@ -2594,14 +2619,15 @@ __device__ __forceinline__ void ScatterMsdBody(const MsdArgs a) {
 // range of the caller's arrays.  Keys (and values) stay in registers between the passes; the staging buffer -- up to
 // 144 KiB -- takes the counters' place inside each pass like in scatter_msd_kernel; key+value stages the values through
 // the same slots after the keys.  A wave takes only as many slots as the bucket needs (like SortInWorkgroup).
-template <int KPT>
+template <int KPT, int THREADS = 1024>
 constexpr size_t BucketSort2LdsWords() {
-  return (size_t)1024 * KPT + 32;
+  return (size_t)THREADS * KPT + 32;
 }
 
-template <uint32_t BITS, int KPT, bool KV>
+template <uint32_t BITS, int KPT, bool KV, int THREADS = 1024>
 __device__ __forceinline__ void BucketSort2Body(const MsdArgs a) {
-  constexpr int THREADS = 1024, WAVES = THREADS / 64;
+  constexpr int WAVES = THREADS / 64;
+  static_assert(THREADS == 1024 || THREADS == 512, "one or two words of a counter row per thread");
   constexpr uint32_t TILE = THREADS * KPT;
   constexpr uint32_t W0 = 11u, W1 = 32u - BITS - W0;
   constexpr uint32_t ROW = 1024;  // 2048 packed counters per wave
@@ -2665,7 +2691,14 @@ __device__ __forceinline__ void BucketSort2Body(const MsdArgs a) {
     LdsBarrier();
     uint32_t firstNow = first;  // (see SortInWorkgroup: keeps the read-back addresses out of registers across the passes)
     asm volatile("" : "+v"(firstNow));
-    if constexpr (!KV) {  // (key+value: the values are live as well; the column is read twice instead of kept)
+    if constexpr (THREADS == 512) {  // two words of the row per thread
+      u32x2 column[WAVES];
+      const u32x2 totals = ColumnPairRead<ROW, WAVES>(counters, tid, column);
+      const uint32_t count0 = totals[0] & 0xFFFFu, count1 = totals[0] >> 16, count2 = totals[1] & 0xFFFFu;
+      const uint32_t local0 = BlockExclusiveScanAll<THREADS>(count0 + count1 + count2 + (totals[1] >> 16), scanScratch + 16 * pass, tid);
+      const uint32_t local2 = local0 + count0 + count1;
+      ColumnPairBasesFrom<ROW, WAVES>(counters, tid, u32x2{local0 | ((local0 + count0) << 16), local2 | ((local2 + count2) << 16)}, column);
+    } else if constexpr (!KV) {  // (key+value: the values are live as well; the column is read twice instead of kept)
       uint32_t column[WAVES];
       const uint32_t totals = ColumnRead<ROW, WAVES>(counters, tid, column);
       const uint32_t count0 = totals & 0xFFFFu;
@@ -2747,6 +2780,14 @@ __global__ __launch_bounds__(1024) void scatter_msd_kernel(MsdArgs a) {
 template <uint32_t BITS, int KPT, bool KV>
 __global__ __launch_bounds__(1024) void bucket_sort2_kernel(MsdArgs a) {
   BucketSort2Body<BITS, KPT, KV>(a);
+}
+// Buckets of no more than 16384 elements (sorts of up to 16.2 M elements by ten bits): workgroups of 512 threads and
+// 64 KiB of LDS, TWO to a CU -- one loads or scans while the other ranks.  A bucket has a fixed cost of 5.7 us in the
+// kernel above (load latency, two column scans, eight barriers), half the time of a bucket of 8192 keys, and with one
+// workgroup per CU nothing runs beside it.
+template <uint32_t BITS, bool KV>
+__global__ __launch_bounds__(512, 2) void bucket_sort2_half_kernel(MsdArgs a) {
+  BucketSort2Body<BITS, kMsdHalfCap / 512, KV, 512>(a);
 }
 
 // ---- the plan's launches double as the first two launches of its fallback ------------------------------
@@ -3264,6 +3305,10 @@ hipError_t PrepareMsd() {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOrderCheckPackedLdsBytes);
   if (e == hipSuccess) e = PrepareMsdBits<10>();
   if (e == hipSuccess) e = PrepareMsdBits<11>();
+  for (int kv = 0; kv < 2 && e == hipSuccess; ++kv)
+    e = hipFuncSetAttribute(kv ? reinterpret_cast<const void*>(&bucket_sort2_half_kernel<10, true>)
+                               : reinterpret_cast<const void*>(&bucket_sort2_half_kernel<10, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BucketSort2LdsWords<kMsdHalfCap / 512, 512>() * 4));
   return e;
 }
 
@@ -3318,6 +3363,11 @@ hipError_t LaunchScatterMsd(hipStream_t stream, bool keyValue, const MsdArgs& ar
 
 hipError_t LaunchBucketSort2(hipStream_t stream, bool keyValue, const MsdArgs& args) {
   constexpr int kKeys = kMsdCapKeys / 1024, kPairs = kMsdCapKeyValue / 1024;
+  if (args.cap == kMsdHalfCap && args.bits == 10) {
+    const void* half = keyValue ? reinterpret_cast<const void*>(&bucket_sort2_half_kernel<10, true>)
+                                : reinterpret_cast<const void*>(&bucket_sort2_half_kernel<10, false>);
+    return Launch(half, 1u << args.bits, 512, BucketSort2LdsWords<kMsdHalfCap / 512, 512>() * 4, stream, args);
+  }
   if (args.cap != (keyValue ? kMsdCapKeyValue : kMsdCapKeys)) return hipErrorInvalidValue;
   const void* kernel;
   if (args.bits == 10)
@@ -3348,7 +3398,7 @@ static hipError_t LaunchMsdFusedBits(hipStream_t stream, bool bucketLaunch, cons
 
 hipError_t LaunchMsdFused(hipStream_t stream, bool bucketLaunch, bool keyValue, const MsdArgs& m, const OnesweepArgs& p,
                           uint32_t passGrid) {
-  if (keyValue || m.tileKeys == 0 || m.tileKeys % 4096u != 0 || m.tileKeys > kMsdTileKeys || m.cap != kMsdCapKeys)
+  if (keyValue || m.tileKeys == 0 || m.tileKeys % 4096u != 0 || m.tileKeys > kMsdTileKeys || (bucketLaunch && m.cap != kMsdCapKeys))
     return hipErrorInvalidValue;  // keys-only sorts only
   if (m.bits == 10) return LaunchMsdFusedBits<10, false>(stream, bucketLaunch, m, p, passGrid);
   if (m.bits == 11) return LaunchMsdFusedBits<11, false>(stream, bucketLaunch, m, p, passGrid);
