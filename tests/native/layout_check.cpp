@@ -62,11 +62,11 @@ int main() {
             ok = ok && (address + l9.inoutOffset) % 128 == 0 && l9.valuesOffset >= l9.inoutOffset + (uint64_t)n * 4;
           }
         }
-        // the MSD plan (MsdBits in vrdx_api.cpp: recorded from 8144129 / 16252929 elements up while the mean bucket of the top ten
+        // the MSD plan (MsdBits in vrdx_api.cpp: recorded from 8144129 elements up while the mean bucket of the top ten
         // -- or else eleven -- bits leaves 3 % of room in 36864, at most 2048 tiles of 32768 keys): its per-tile counts
         // (16 bits per tile and bucket) and its bucket table sit in front of the status regions of whatever passes are
         // recorded behind it, and all of it must fit at every alignment
-        if (g.keysPerThread == 32 && n >= 8144129u && vrdx::RoundUp(n, 32768u) <= 2048u) {  // (keys-only from 8.14 M, key+value from 16.25 M)
+        if (g.keysPerThread == 32 && n >= 8144129u && vrdx::RoundUp(n, 32768u) <= 2048u) {  // (keys-only and key+value from 8.14 M)
           uint32_t bits = 0;
           for (uint32_t b = 10; b <= 11 && bits == 0; ++b)
             if ((((uint64_t)n + (1u << b) - 1) >> b) * 103 / 100 <= 36864) bits = b;

@@ -277,7 +277,8 @@ int Parity(Harness& h, bool quick) {
     sizes.push_back((1u << 23) + (1u << 21) + 77);
     sizes.push_back((1u << 24) + 70001);
     sizes.push_back(3u * (1u << 23) + 200003);
-    // the nine-bit hybrid plan (8.1 M < N <= 16.2 M): the sizes above from 2^23 + 4097 to 2^24 take it; one just below its end
+    // 8.1 M < N <= 16.3 M: the MSD plan with the half-size bucket kernel (the nine-bit hybrid plan with VRDX_MSD=0); the sizes above
+    // from 2^23 + 4097 to 2^24 take it; one just below the nine-bit plan's end
     sizes.push_back(16200000);
   }
   for (uint32_t n : sizes) {
@@ -363,7 +364,7 @@ int Parity(Harness& h, bool quick) {
   return failures;
 }
 
-// The MSD plan (16.25 M elements and more): uniform keys at sizes on both sides of its ten- / eleven-bit ranges in every
+// The MSD plan (8.15 M elements and more): uniform keys at sizes on both sides of its ten- / eleven-bit ranges in every
 // mode, and inputs the DEVICE must turn it down for (a bucket beyond the capacity: the four passes recorded behind it run).
 // argv sizes override the list.
 int MsdParity(Harness& h, const std::vector<uint32_t>& wanted) {
@@ -374,7 +375,7 @@ int MsdParity(Harness& h, const std::vector<uint32_t>& wanted) {
     std::fflush(stdout);
   };
   std::vector<uint32_t> sizes = wanted;
-  if (sizes.empty()) sizes = {16252929u, 20000003u, 1u << 25, 36000001u, 45000000u};
+  if (sizes.empty()) sizes = {8144129u, 16288768u, 16288769u, 20000003u, 1u << 25, 36000001u, 45000000u};
   for (uint32_t n : sizes) {
     std::vector<uint32_t> v;
     auto k = Mt(n, 1, 32, &v);

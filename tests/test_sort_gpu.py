@@ -111,7 +111,7 @@ def decline_msd(keys):
 
 
 def plan_word(storage):
-    """word 1 of the storage: 3 = a plan in front of the passes (nine-bit, MSD) took the sort"""
+    """word 1 of the storage: 3 = the plan recorded in front of the passes (MSD; nine-bit with VRDX_MSD=0) took the sort"""
     return int(storage[4:8].cpu().numpy().view(np.uint32)[0])
 
 
@@ -532,6 +532,17 @@ def test_four_pass_plan_at_mid_sizes_with_the_hybrid_plan_switched_off():
     assert out.returncode == 0 and ", 0 failures" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def test_nine_bit_hybrid_plan_with_the_msd_plan_switched_off():
+    """VRDX_MSD=0: sorts of 8.4 M < N <= 16.2 M elements record round 4's nine-bit hybrid plan again (scatter9_kernel, then
+    512 sub-buckets of at most 32768 elements; superseded by the MSD plan with the half-size bucket kernel and kept as its
+    measurement baseline).  The native battery of uniform keys in every mode, duplicates (stability) and the inputs the
+    device must turn the plan down for (24-bit keys, one heavy bucket, descending keys)."""
+    exe = os.path.join(ROOT, "tests", "native", "vrdx_selftest")
+    out = subprocess.run([exe, "msd", "12000003", "16200000"], capture_output=True, text=True, timeout=1200,
+                         env=dict(os.environ, VRDX_MSD="0"))
+    assert out.returncode == 0 and ", 0 failures" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 @pytest.mark.parametrize("n", [256 * 1024 * 20, 256 * 1024 * 20 + 1, 256 * 1024 * 28 - 5, 256 * 2048 * 20, 256 * 2048 * 24 + 1,
                                256 * 2048 * 32 - 4095])
 def test_even_split_tiles_at_their_slot_boundaries(torch_mod, sorter, oracle, n):
@@ -655,16 +666,16 @@ def test_block_sums_in_sorts_of_one_round(torch_mod, sorter, oracle, n):
     key+value), the two-sub-tile kernel's even-split tiles from 129 tiles up to 256 full ones; direct and indirect with
     a smaller count (whole blocks of 32 tiles past the count).  Values = iota: the permutation itself."""
     k, _ = oracle.generate(17, n, 32)
-    # (uniform keys of these sizes would take the nine-bit hybrid plan recorded in front of the passes: one nine-bit value
-    # occurring 40000 times sends the sort down its four passes, which is where the block sums are)
-    # (the same top ELEVEN bits: the sizes from 16.25 M up record the MSD plan instead, whose buckets are ten bits wide)
+    # (uniform keys of these sizes take the MSD plan recorded in front of the passes: one value of the top ELEVEN bits
+    # occurring 40000 times -- more than either bucket capacity -- sends the sort down its four passes, which is where the
+    # block sums are)
     k[:: max(1, n // 40000)][:40000] = (k[:: max(1, n // 40000)][:40000] & np.uint32(0x001FFFFF)) | np.uint32(0x0AB << 23)
     iota = np.arange(n, dtype=np.uint32)
     kept = []
     ek, _, _ = oracle.sort(k)
     gk, _ = gpu_sort(torch_mod, sorter, k, storage_out=kept)
     assert np.array_equal(gk, ek)
-    assert int(kept[0][4:8].cpu().numpy().view(np.uint32)[0]) != 3   # the four passes ran, not the nine-bit plan
+    assert int(kept[0][4:8].cpu().numpy().view(np.uint32)[0]) != 3   # the four passes ran, not the plan in front of them
     check_against_oracle(torch_mod, sorter, oracle, k, iota)
     count = n - n // 3 - 7
     check_against_oracle(torch_mod, sorter, oracle, k, count=count, indirect=True, max_count=n)

@@ -208,6 +208,7 @@ uint32_t HybridCapacity(bool atomicRank, uint32_t elementCount) {
 // point where a bucket of the top byte no longer fits a workgroup: recorded -- in front of the passes, which return on its
 // verdict -- for sorts beyond the eight-bit plan's reach whose mean sub-bucket N / 512 leaves 3 % of room in 32768
 // (one round of 32768-element tiles < N <= 16.2 M elements; one-atomic ranking only, like the 32768-element buckets).  Returns the capacity or 0.
+// Since the MSD plan covers these sizes (MsdBits) this plan is recorded only with VRDX_MSD=0: its measurement baseline.
 // Measured (profiles/r04_nine_bit_plan.txt): key+value 0.80-0.83 x the time of the four passes over the whole range
 // (58-76 instead of 48-62 GItems/s), keys-only 0.90-0.95 x (its scatter by nine bits is no match for a pass of the
 // two-sub-tile kernel -- 43 against 29 us at 12.6 M keys -- and the four returning passes cost 4.4 us each).
@@ -251,7 +252,7 @@ uint32_t MsdBits(bool atomicRank, bool keyValue, uint32_t elementCount, uint32_t
   static const int forcedBits = TuningKnob("VRDX_MSD_BITS");  // measurements: 10 | 11 wherever the capacity allows
   static const int knobLast = TuningKnob("VRDX_HYBRID_HEADROOM_LAST");
   if (!enabled || !atomicRank) return 0;
-  // From where the EIGHT-bit plan ends (8.1 M: hybridCap == 0), keys-only and key+value.  Up to 16.2 M elements the buckets
+  // From where the EIGHT-bit plan ends (8.1 M: hybridCap == 0), keys-only and key+value.  Up to 16.29 M elements the buckets
   // hold at most 16384 and the half-size bucket kernel sorts them, two workgroups to a CU: with it the plan is 8-15 % faster
   // than the nine-bit plan and the four passes at one round of tiles, which key+value sorts of these sizes took before
   // (profiles/r05_msd_half_buckets.txt); the nine-bit plan is recorded only with VRDX_MSD=0.
