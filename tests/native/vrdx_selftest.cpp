@@ -375,7 +375,7 @@ int MsdParity(Harness& h, const std::vector<uint32_t>& wanted) {
     std::fflush(stdout);
   };
   std::vector<uint32_t> sizes = wanted;
-  if (sizes.empty()) sizes = {8144129u, 16288768u, 16288769u, 20000003u, 1u << 25, 36000001u, 45000000u};
+  if (sizes.empty()) sizes = {8144129u, 18325504u, 18325505u, 20000003u, 1u << 25, 36000001u, 45000000u};
   for (uint32_t n : sizes) {
     std::vector<uint32_t> v;
     auto k = Mt(n, 1, 32, &v);

@@ -252,8 +252,8 @@ uint32_t MsdBits(bool atomicRank, bool keyValue, uint32_t elementCount, uint32_t
   static const int forcedBits = TuningKnob("VRDX_MSD_BITS");  // measurements: 10 | 11 wherever the capacity allows
   static const int knobLast = TuningKnob("VRDX_HYBRID_HEADROOM_LAST");
   if (!enabled || !atomicRank) return 0;
-  // From where the EIGHT-bit plan ends (8.1 M: hybridCap == 0), keys-only and key+value.  Up to 16.29 M elements the buckets
-  // hold at most 16384 and the half-size bucket kernel sorts them, two workgroups to a CU: with it the plan is 8-15 % faster
+  // From where the EIGHT-bit plan ends (8.1 M: hybridCap == 0), keys-only and key+value.  Up to 18.3 M elements the buckets
+  // hold at most 18432 and the half-size bucket kernel sorts them, two workgroups to a CU: with it the plan is 8-15 % faster
   // than the nine-bit plan and the four passes at one round of tiles, which key+value sorts of these sizes took before
   // (profiles/r05_msd_half_buckets.txt); the nine-bit plan is recorded only with VRDX_MSD=0.
   const uint32_t lowest = from > 0 ? (uint32_t)from : (hybridCap == 0 ? vrdx::kSmallSortMaxElements + 1u : ~0u);

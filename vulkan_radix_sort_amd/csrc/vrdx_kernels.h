@@ -156,7 +156,7 @@ constexpr uint32_t kMsdTileKeys = 32768;   // a scatter tile's capacity: 1024 th
 constexpr uint32_t kMsdMaxTiles = 2048;    // spine_msd_kernel: 64 chunks of at most 32 rows
 constexpr uint32_t kMsdCapKeys = 36864;    // bucket capacity, keys-only: 1024 threads x 36 keys (144 KiB of staging)
 constexpr uint32_t kMsdCapKeyValue = 36864;  // the same for pairs: keys and values take turns in the staging buffer
-constexpr uint32_t kMsdHalfCap = 16384;    // buckets of the half-size bucket kernel: 512 threads x 32 elements, two workgroups per CU
+constexpr uint32_t kMsdHalfCap = 18432;    // buckets of the half-size bucket kernel: 512 threads x 36 elements (72 KiB of staging), two workgroups per CU
 struct MsdArgs {
   uint32_t* keysCaller;
   uint32_t* keysScratch;
