@@ -1,5 +1,5 @@
 #!/bin/bash
-# profiles/r05_msd_plan.txt: (1) 19 sizes from 2^23 to 2^26, keys-only and key+value, reference protocol, with the per-stage
+# profiles/r05_msd_plan.txt: (1) 20 sizes from 2^23 to 2^26, keys-only and key+value, reference protocol, with the per-stage
 # times of the 15-slot timestamp contract; (2) what the scatter through memory costs by digit width -- nine bits (the nine-bit
 # hybrid plan's scatter9_kernel), ten and eleven (scatter_msd_kernel) -- at 16 M elements, and ten against eleven at 2^25.
 set -u
@@ -10,7 +10,7 @@ T=$ROOT/tests/native/vrdx_selftest
 F=$OUT/msd_plan.txt
 echo "# (1) vrdx_selftest bench: 1 warm-up + 10 timed runs on fresh mt19937 data, median; stage ms from the 15 timestamps" > $F
 echo "#     (MSD plan: histogram | spine scatter buckets fallback; other plans: histogram | the four pass launches)" >> $F
-SIZES="8388608 9437184 10485760 12582912 14680064 16252928 16252929 16777216 18874368 20971520 23068672 25165824 27262976 29360128 31457280 33554432 36600000 41943040 67108864"
+SIZES="8388608 9437184 10485760 12582912 14680064 16252928 16777216 18325504 18325505 18874368 20971520 23068672 25165824 27262976 29360128 31457280 33554432 36600000 41943040 67108864"
 timeout 1500 $T bench $SIZES >> $F 2>&1
 echo "# the same sizes with VRDX_MSD=0 (round 4's plans: nine-bit hybrid up to 16.2 M, four passes beyond)" >> $F
 VRDX_MSD=0 timeout 1500 $T bench $SIZES >> $F 2>&1
@@ -29,8 +29,9 @@ PY
 }
 echo "# (2) the scatter through memory by digit width (rocprofv3 --kernel-trace --stats of vrdx_selftest bench N; keys-only = ...false>, key+value = ...true>)" >> $F
 prof 16000000 "nine bits: scatter9_kernel + bucket_sort_kernel<...,512> (three in-LDS passes)" VRDX_MSD=0
-prof 16000000 "ten bits: scatter_msd_kernel<10> + bucket_sort2_kernel<10> (two in-LDS passes)" VRDX_MSD_FROM=1
-prof 16000000 "eleven bits" VRDX_MSD_FROM=1 VRDX_MSD_BITS=11
+prof 16000000 "ten bits: scatter_msd_kernel<10> + bucket_sort2_half_kernel<10> (two in-LDS passes, two workgroups per CU)" VRDX_MSD=1
+prof 16000000 "ten bits with the full-size bucket kernel, one workgroup per CU" VRDX_MSD_HALF=0
+prof 16000000 "eleven bits (full-size bucket kernel)" VRDX_MSD_BITS=11
 prof 33554432 "ten bits" VRDX_MSD=1
 prof 33554432 "eleven bits" VRDX_MSD_BITS=11
 cat $F
