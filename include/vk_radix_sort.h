@@ -225,7 +225,7 @@ uint64_t vrdxHipEventOverheadNs(VkCommandBuffer commandBuffer);
 #define VRDX_HIP_PLAN_ONE_WORKGROUP 1u /* <= 16384 elements: one launch, one load and one store of the data */
 #define VRDX_HIP_PLAN_FOUR_PASSES 2u   /* fused histogram + four onesweep passes: 36 B/key, 68 B/pair */
 #define VRDX_HIP_PLAN_HYBRID8 3u       /* histogram + one scatter by the highest varying byte + one in-LDS sort per bucket */
-#define VRDX_HIP_PLAN_HYBRID9 4u       /* the same with the top nine bits, 512 buckets (recorded only with VRDX_MSD=0 since the MSD plan covers its sizes) */
+#define VRDX_HIP_PLAN_HYBRID9 4u       /* round 4's nine-bit hybrid plan: no longer built (the MSD plan took its sizes); never reported, the value stays reserved */
 #define VRDX_HIP_PLAN_MSD 5u           /* histogram + scatter by the top 10 / 11 bits + two in-LDS passes per bucket */
 typedef struct VrdxHipPlanInfo {
   uint32_t plan;                    /* VRDX_HIP_PLAN_* */

@@ -47,23 +47,8 @@ int main() {
             ok = ok && plan.tiles - plan.fullTiles <= cus;
           }
         }
-        // the nine-bit hybrid plan (Hybrid9Capacity in vrdx_api.cpp: recorded for sorts of more than one round of
-        // 32768-element tiles whose mean nine-bit sub-bucket leaves 3 % of room in 32768, next to passes of 32768-key tiles
-        // and more): its 512 counts and its status rows of 2 KiB per tile must fit as well, at every alignment
-        if (g.keysPerThread == 32 && (uint64_t)n > (uint64_t)cus * 32768u && ((uint64_t)(n + 511) / 512) * 103 / 100 <= 32768) {
-          const uint64_t tiles9 = vrdx::RoundUp(n, vrdx::Scatter9Slots(n, cus) * 1024u);
-          for (uint32_t address = 0; address < 128; address += 16) {
-            const vrdx::StorageLayout l9 =
-                vrdx::MakeLayout(n, VRDX_STORAGE_ALIGN, plan.tiles, 0x7f0000001000ull + address, plan.blockSums, tiles9);
-            ++cases;
-            ok = ok && vrdx::LayoutFits(l9, n) && l9.top9Offset == 16 + 4096 && l9.clearBytes == 16 + 4096 + 2048;
-            ok = ok && (address + l9.status9Offset) % 128 == 0 && l9.status9Bytes == (tiles9 - 1) * 2048;
-            ok = ok && l9.statusOffset == l9.status9Offset + l9.status9Bytes && l9.statusClearBytes == l9.status9Bytes + l9.regionBytes;
-            ok = ok && (address + l9.inoutOffset) % 128 == 0 && l9.valuesOffset >= l9.inoutOffset + (uint64_t)n * 4;
-          }
-        }
         // the MSD plan (MsdBits in vrdx_api.cpp: recorded from 8144129 elements up while the mean bucket of the top ten
-        // -- or else eleven -- bits leaves 3 % of room in 36864, at most 2048 tiles of 32768 keys): its per-tile counts
+        // -- or else eleven -- bits leaves 3 % of room in the bucket capacity, at most 2048 tiles of 32768 keys): its per-tile counts
         // (16 bits per tile and bucket) and its bucket table sit in front of the status regions of whatever passes are
         // recorded behind it, and all of it must fit at every alignment
         if (g.keysPerThread == 32 && n >= 8144129u && vrdx::RoundUp(n, 32768u) <= 2048u) {  // (keys-only and key+value from 8.14 M)
@@ -76,7 +61,7 @@ int main() {
           ok = ok && msdTileKeys % 4096u == 0 && msdTileKeys >= 4096u && msdTileKeys <= 32768u && msdTiles <= 2048u;
           for (uint32_t address = 0; bits != 0 && address < 128; address += 16) {
             const vrdx::StorageLayout lm = vrdx::MakeLayout(n, VRDX_STORAGE_ALIGN, plan.tiles, 0x7f0000001000ull + address,
-                                                            plan.blockSums, 0, bits, msdTiles);
+                                                            plan.blockSums, bits, msdTiles);
             ++cases;
             ok = ok && vrdx::LayoutFits(lm, n) && lm.clearBytes == 16 + 4096;
             ok = ok && (address + lm.msdCountsOffset) % 128 == 0 && lm.msdCountsBytes == msdTiles * ((uint64_t)2 << bits);

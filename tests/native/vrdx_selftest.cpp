@@ -277,8 +277,7 @@ int Parity(Harness& h, bool quick) {
     sizes.push_back((1u << 23) + (1u << 21) + 77);
     sizes.push_back((1u << 24) + 70001);
     sizes.push_back(3u * (1u << 23) + 200003);
-    // 8.1 M < N <= 16.3 M: the MSD plan with the half-size bucket kernel (the nine-bit hybrid plan with VRDX_MSD=0); the sizes above
-    // from 2^23 + 4097 to 2^24 take it; one just below the nine-bit plan's end
+    // 8.1 M < N <= 18.3 M: the MSD plan with the half-size bucket kernel; the sizes above from 2^23 + 4097 to 2^24 take it
     sizes.push_back(16200000);
   }
   for (uint32_t n : sizes) {
@@ -355,7 +354,7 @@ int Parity(Harness& h, bool quick) {
     run(Mode::Keys, k, v, 300000, "storage reuse");
   }
   for (int kv = 0; kv < 2; ++kv)
-    for (uint32_t n : {5000u, 200000u, 3000000u, 12000000u}) {  // one launch | eight-bit hybrid plan | ... | nine-bit plan
+    for (uint32_t n : {5000u, 200000u, 3000000u, 12000000u}) {  // one launch | eight-bit hybrid plan | ... | MSD plan, half-size buckets
       if (quick && n > 3000000u) continue;
       ++cases;
       if (!GraphCase(h, kv != 0, n)) ++failures;
@@ -736,7 +735,7 @@ int Adversarial(Harness& h, int lg) {
 // against the oracle -- hunts rare cross-workgroup races (status hand-off, ticket, LDS ranking)
 // that a single pass over the parity battery could miss.  Two streams alternate so that sorts of
 // different sizes overlap on the device.
-// maxN: largest element count drawn (3 M by default; 20 M reaches the nine-bit plan, the tail split and block sums, at a
+// maxN: largest element count drawn (3 M by default; 40 M reaches the MSD plan with both bucket kernels, the tail split and block sums, at a
 // few seconds of oracle time per sort).
 int Soak(Harness& h, int seconds, uint32_t maxN = 3u << 20) {
   std::mt19937 g(12345);

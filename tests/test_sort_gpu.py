@@ -111,7 +111,7 @@ def decline_msd(keys):
 
 
 def plan_word(storage):
-    """word 1 of the storage: 3 = the plan recorded in front of the passes (MSD; nine-bit with VRDX_MSD=0) took the sort"""
+    """word 1 of the storage: 3 = the MSD plan recorded in front of the passes took the sort"""
     return int(storage[4:8].cpu().numpy().view(np.uint32)[0])
 
 
@@ -532,11 +532,11 @@ def test_four_pass_plan_at_mid_sizes_with_the_hybrid_plan_switched_off():
     assert out.returncode == 0 and ", 0 failures" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
-def test_nine_bit_hybrid_plan_with_the_msd_plan_switched_off():
-    """VRDX_MSD=0: sorts of 8.4 M < N <= 16.2 M elements record round 4's nine-bit hybrid plan again (scatter9_kernel, then
-    512 sub-buckets of at most 32768 elements; superseded by the MSD plan with the half-size bucket kernel and kept as its
-    measurement baseline).  The native battery of uniform keys in every mode, duplicates (stability) and the inputs the
-    device must turn the plan down for (24-bit keys, one heavy bucket, descending keys)."""
+def test_four_pass_plan_at_large_sizes_with_the_msd_plan_switched_off():
+    """VRDX_MSD=0: sorts beyond the eight-bit plan's reach record the four passes alone (what N > 67 M runs, and what the MSD
+    plan's tables are measured against).  The native battery of uniform keys in every mode, duplicates (stability), 24-bit
+    keys (a trivial pass), one heavy bucket and descending keys at 12 M (one and a half rounds of tiles: tail split) and
+    16.2 M elements."""
     exe = os.path.join(ROOT, "tests", "native", "vrdx_selftest")
     out = subprocess.run([exe, "msd", "12000003", "16200000"], capture_output=True, text=True, timeout=1200,
                          env=dict(os.environ, VRDX_MSD="0"))

@@ -35,9 +35,7 @@ CSRC = os.path.join(ROOT, "vulkan_radix_sort_amd", "csrc")
 # every kernel the launcher (vrdx_module_launch.inc) can ask for, by mangled name
 def expected_kernels():
     names = ["_ZN4vrdx22lds_order_check_kernelEPjS0_", "_ZN4vrdx11spin_kernelEPyj"]
-    names += ["_ZN4vrdx16histogram_kernelILj%uELb%dEEEvPKjjS2_PjS3_PDv4_jjS3_" % (c, nine) for c in (8, 32) for nine in (0, 1)]
-    names += ["_ZN4vrdx15scatter9_kernelILb%dEEEvNS_12OnesweepArgsE" % kv for kv in (0, 1)]
-    names += ["_ZN4vrdx18bucket_sort_kernelILi1024ELi32ELb%dELb1ELi512EEEvNS_14BucketSortArgsE" % kv for kv in (0, 1)]
+    names += ["_ZN4vrdx16histogram_kernelILj%uEEEvPKjjS2_PjS3_PDv4_jj" % c for c in (8, 32)]
     for threads, kpt, sub in ((1024, 8, 1), (1024, 16, 1), (1024, 32, 1), (1024, 32, 2)):
         for kv in (0, 1):
             for atomic in (0, 1):
@@ -61,11 +59,11 @@ def expected_kernels():
         for kernel in ("27msd_scatter_or_pass0_kernel", "27msd_buckets_or_pass1_kernel"):  # keys-only: the plan's launch or a pass of its fallback
             names += ["_ZN4vrdx%sILj%dELb0ELb%dEEEvNS_7MsdArgsENS_12OnesweepArgsE" % (kernel, bits, dyn) for dyn in (0, 1)]
     for kv in (0, 1):  # 32768-element buckets: one-atomic ranking only
-        names.append("_ZN4vrdx18bucket_sort_kernelILi1024ELi32ELb%dELb1ELi256EEEvNS_14BucketSortArgsE" % kv)
+        names.append("_ZN4vrdx18bucket_sort_kernelILi1024ELi32ELb%dELb1EEEvNS_14BucketSortArgsE" % kv)
     for kpt in (4, 8, 16):
         for kv in (0, 1):
             for atomic in (0, 1):
-                names.append("_ZN4vrdx18bucket_sort_kernelILi1024ELi%dELb%dELb%dELi256EEEvNS_14BucketSortArgsE" % (kpt, kv, atomic))
+                names.append("_ZN4vrdx18bucket_sort_kernelILi1024ELi%dELb%dELb%dEEEvNS_14BucketSortArgsE" % (kpt, kv, atomic))
     for threads in (256, 1024):
         for kv in (0, 1):
             for atomic in (0, 1):

@@ -100,10 +100,9 @@ int ForcedConfigIndex() {
 //    (1, 2], just below 4 or 6.
 enum : int { kCfg1024x8 = 0, kCfg1024x16 = 1, kCfg1024x32 = 2, kCfg1024x32x2 = 3 };
 
-// nineBit: the nine-bit hybrid plan is recorded in front of the passes, which are then only the fallback for skewed keys;
-// its status rows take half of the reference's partition-histogram area, so the passes must not take tiles of 16384.
-int ConfigIndex(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount, bool atomicRank, bool nineBit = false,
-                bool msd = false) {
+// msd: the MSD plan is recorded in front of the passes, which are then only the fallback for skewed keys; its per-tile counts
+// take a quarter to a half of the reference's partition-histogram area, so the passes must not take tiles of 16384.
+int ConfigIndex(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount, bool atomicRank, bool msd = false) {
   const int forced = ForcedConfigIndex();
   // (the two-sub-tile kernel is keys-only: a key+value sort under a forced 1024x32x2 takes 1024x32)
   if (forced >= 0) return forced == kCfg1024x32x2 && (keyValue || !atomicRank) ? kCfg1024x32 : forced;
@@ -114,7 +113,7 @@ int ConfigIndex(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount
     // just past one round of 32768-element tiles, two workgroups of 16384 per CU fill the second round's gap
     // (1.2-2.6 % at 1.07 <= f <= 1.32, profiles/r03_sweep_by_geometry.txt; still so with the tail split of round 4,
     // profiles/r04_tail_split_kv.txt)
-    if (f > 1.0 && f <= 1.35 && !nineBit) return kCfg1024x16;
+    if (f > 1.0 && f <= 1.35 && !msd) return kCfg1024x16;
     return kCfg1024x32;
   }
   // Behind the MSD plan the passes are the fallback only, and the plan's own launches double as its first two (one kernel, two
@@ -204,34 +203,10 @@ uint32_t HybridCapacity(bool atomicRank, uint32_t elementCount) {
   return needLast <= largest ? largest : 0u;
 }
 
-// The nine-bit hybrid plan (scatter9_kernel + 512 sub-bucket sorts, vrdx_kernels.hip) carries the two-trip plan past the
-// point where a bucket of the top byte no longer fits a workgroup: recorded -- in front of the passes, which return on its
-// verdict -- for sorts beyond the eight-bit plan's reach whose mean sub-bucket N / 512 leaves 3 % of room in 32768
-// (one round of 32768-element tiles < N <= 16.2 M elements; one-atomic ranking only, like the 32768-element buckets).  Returns the capacity or 0.
-// Since the MSD plan covers these sizes (MsdBits) this plan is recorded only with VRDX_MSD=0: its measurement baseline.
-// Measured (profiles/r04_nine_bit_plan.txt): key+value 0.80-0.83 x the time of the four passes over the whole range
-// (58-76 instead of 48-62 GItems/s), keys-only 0.90-0.95 x (its scatter by nine bits is no match for a pass of the
-// two-sub-tile kernel -- 43 against 29 us at 12.6 M keys -- and the four returning passes cost 4.4 us each).
-// VRDX_HYBRID=0 and a forced tile geometry switch it off with the eight-bit plan, VRDX_HYBRID9=0 alone.
-uint32_t Hybrid9Capacity(bool atomicRank, uint32_t elementCount, uint32_t hybridCap, uint32_t cus) {
-  static const bool enabled = [] {
-    const char* all = std::getenv("VRDX_HYBRID");
-    const char* nine = std::getenv("VRDX_HYBRID9");
-    return (all == nullptr || all[0] != '0') && (nine == nullptr || nine[0] != '0');
-  }();
-  // (not for sorts of exactly one round of 32768-element tiles or less: there the four passes are at their best -- one
-  // round, block sums -- and as fast (keys-only) or 5 % faster (key+value) than the nine-bit plan)
-  if (!enabled || !atomicRank || hybridCap != 0 || (uint64_t)elementCount <= (uint64_t)cus * 32768u) return 0;
-  static const int knobLast = TuningKnob("VRDX_HYBRID_HEADROOM_LAST");
-  const uint64_t mean = (elementCount + 511u) / 512u;
-  const uint64_t need = mean * (uint64_t)(knobLast > 0 ? knobLast : 103) / 100u;
-  return need <= 32768u ? 32768u : 0u;
-}
-
 // The MSD plan (vrdx_kernels.hip, "MSD plan"): one stable scatter by the keys' top 10 or 11 bits, then every bucket by its
 // remaining bits in two passes inside one workgroup -- three ranking steps and two trips through memory instead of four
-// and four.  Recorded, in front of the four passes (which return on its verdict), for sorts beyond the eight- and nine-bit
-// plans' reach whose mean bucket leaves 3 % of room in the bucket kernel's capacity (uniform keys spread by half a percent
+// and four.  Recorded, in front of the four passes (which return on its verdict), for sorts beyond the eight-bit
+// plan's reach whose mean bucket leaves 3 % of room in the bucket kernel's capacity (uniform keys spread by half a percent
 // at these sizes): ten bits up to 36.6 M keys / 32.5 M pairs, eleven bits up to twice that.  Returns the bits or 0.
 // One-atomic ranking only.  VRDX_MSD=0 switches it off (VRDX_HYBRID=0 and a forced tile geometry as well); VRDX_MSD_FROM=n
 // records it from n elements up instead (measurements: below its default range it replaces the other two plans).
@@ -254,8 +229,8 @@ uint32_t MsdBits(bool atomicRank, bool keyValue, uint32_t elementCount, uint32_t
   if (!enabled || !atomicRank) return 0;
   // From where the EIGHT-bit plan ends (8.1 M: hybridCap == 0), keys-only and key+value.  Up to 18.3 M elements the buckets
   // hold at most 18432 and the half-size bucket kernel sorts them, two workgroups to a CU: with it the plan is 8-15 % faster
-  // than the nine-bit plan and the four passes at one round of tiles, which key+value sorts of these sizes took before
-  // (profiles/r05_msd_half_buckets.txt); the nine-bit plan is recorded only with VRDX_MSD=0.
+  // than round 4's nine-bit hybrid plan and the four passes at one round of tiles, which key+value sorts of these sizes
+  // took before (profiles/r05_msd_half_buckets.txt); that plan's kernels are gone since.
   const uint32_t lowest = from > 0 ? (uint32_t)from : (hybridCap == 0 ? vrdx::kSmallSortMaxElements + 1u : ~0u);
   if (elementCount < lowest || vrdx::RoundUp(elementCount, vrdx::kMsdTileKeys) > vrdx::kMsdMaxTiles) return 0;
   const uint32_t cap = keyValue ? vrdx::kMsdCapKeyValue : vrdx::kMsdCapKeys;
@@ -381,10 +356,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   const uint32_t hybridCap = ForcedConfigIndex() < 0 ? HybridCapacity(atomicRank, elementCount) : 0u;
   uint32_t msdBits = ForcedConfigIndex() < 0 ? MsdBits(atomicRank, keyValue, elementCount, hybridCap, &msdCap) : 0u;
   if (hybridCap != 0) msdBits = 0;  // (VRDX_MSD_FROM below the eight-bit plan's end: that plan keeps its sizes)
-  uint32_t cap9 = ForcedConfigIndex() < 0 && msdBits == 0
-                      ? Hybrid9Capacity(atomicRank, elementCount, hybridCap, (uint32_t)sorter->computeUnits)
-                      : 0u;
-  const int configIndex = ConfigIndex(sorter, keyValue, elementCount, atomicRank, cap9 != 0 || msdBits != 0, msdBits != 0);
+  const int configIndex = ConfigIndex(sorter, keyValue, elementCount, atomicRank, msdBits != 0);
   vrdx::TilePlan tilePlan = PlanTiles(sorter, configIndex, keyValue, elementCount, atomicRank);
   // Block sums instead of the look-back chain: sorts of one round (PlanTiles) on the four-pass plan -- with a hybrid
   // plan recorded, launch 0 may rank by another byte than its pass index, which the block-sum form does not look up.
@@ -392,24 +364,16 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   static const int blockSumsKnob = TuningKnob("VRDX_BLOCK_SUMS");
   bool blockSums = tilePlan.blockSums && hybridCap == 0 && blockSumsKnob != 0;
   uint8_t* const storage = BufferAddress(storageBuffer, storageOffset);
-  static const int slots9Knob = TuningKnob("VRDX_SCATTER9_SLOTS");  // measurements: 8 ... 32, a multiple of four
-  const uint32_t slots9 = slots9Knob >= 8 && slots9Knob <= 32 && slots9Knob % 4 == 0
-                              ? (uint32_t)slots9Knob
-                              : vrdx::Scatter9Slots(elementCount, (uint32_t)sorter->computeUnits);
-  uint32_t tiles9 = cap9 != 0 ? vrdx::RoundUp(elementCount, slots9 * 1024u) : 0u;
   const uint32_t msdTileKeys = MsdTileKeys(elementCount, (uint32_t)sorter->computeUnits);
   const uint32_t msdTiles = vrdx::RoundUp(elementCount, msdTileKeys);
   vrdx::StorageLayout layout = vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, tilePlan.tiles,
-                                                (uint64_t)reinterpret_cast<uintptr_t>(storage), blockSums, tiles9, msdBits,
-                                                msdTiles);
-  if ((cap9 != 0 || msdBits != 0) && !vrdx::LayoutFits(layout, elementCount)) {
-    // (cannot happen for the sizes Hybrid9Capacity / MsdBits admit -- tests/native/layout_check.cpp sweeps them -- but the
-    // storage is the caller's: without the plans' rows in front of the status regions the layout fits for every N)
-    cap9 = 0;
-    tiles9 = 0;
+                                                (uint64_t)reinterpret_cast<uintptr_t>(storage), blockSums, msdBits, msdTiles);
+  if (msdBits != 0 && !vrdx::LayoutFits(layout, elementCount)) {
+    // (cannot happen for the sizes MsdBits admits -- tests/native/layout_check.cpp sweeps them -- but the storage is the
+    // caller's: without the plan's rows in front of the status regions the layout fits for every N)
     msdBits = 0;
     layout = vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, tilePlan.tiles,
-                              (uint64_t)reinterpret_cast<uintptr_t>(storage), blockSums, 0);
+                              (uint64_t)reinterpret_cast<uintptr_t>(storage), blockSums);
   }
   uint32_t* const keys = reinterpret_cast<uint32_t*>(BufferAddress(keysBuffer, keysOffset));
   uint32_t* const values =
@@ -470,7 +434,6 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   Stamp(pool, query + 1, stream);
 
   uint32_t* const globalHistogram = reinterpret_cast<uint32_t*>(storage + layout.histogramOffset);
-  uint32_t* const top9Table = cap9 != 0 ? reinterpret_cast<uint32_t*>(storage + layout.top9Offset) : nullptr;
   uint32_t* const status = reinterpret_cast<uint32_t*>(storage + layout.statusOffset);
   uint32_t* const tickets = reinterpret_cast<uint32_t*>(storage + layout.ticketOffset);
   uint32_t* const failure = reinterpret_cast<uint32_t*>(storage + layout.failureOffset);
@@ -504,7 +467,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     } else {
       EnqueueCheck(sorter, "histogram_kernel",
                    vrdx::LaunchHistogram(stream, grid, keys, elementCount, countPtr, globalHistogram, tickets,
-                                         storage + layout.statusClearOffset, (uint32_t)layout.statusClearBytes, top9Table));
+                                         storage + layout.statusClearOffset, (uint32_t)layout.statusClearBytes));
     }
   }
 
@@ -516,43 +479,6 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   bool earlyValues = true;
   static const int forcedEarly = TuningKnob("VRDX_KV_EARLY_VALUES");  // 0 | 1: tuning/testing
   if (forcedEarly >= 0) earlyValues = forcedEarly != 0;
-  // The nine-bit hybrid plan, recorded in front of the passes: one scatter by the top nine bits, then 512 sub-bucket
-  // sorts.  Both launches decide on the device whether the plan applies (no nine-bit value occurs more than cap9 times);
-  // if it does, every launch of the four passes returns on the verdict word, if not, these two return and the passes
-  // run as if nothing had been recorded in front of them.  (Timestamps: both fall into the "upsweep" slot of pass 0.)
-  vrdx::OnesweepArgs nine;
-  std::memset(&nine, 0, sizeof(nine));
-  if (cap9 != 0) {
-    nine.keysCaller = keys;
-    nine.keysScratch = keysScratch;
-    nine.valuesCaller = keyValue ? values : nullptr;
-    nine.valuesScratch = keyValue ? valuesScratch : nullptr;
-    nine.maxCount = elementCount;
-    nine.countPtr = countPtr;
-    nine.histogramTable = globalHistogram;
-    nine.statusCur = reinterpret_cast<uint32_t*>(storage + layout.status9Offset);
-    nine.ticketCur = tickets + 2;  // its own ticket word in the ticket line (zeroed by the histogram kernel)
-    nine.failure = failure;
-    nine.stickyFailure = sorter->stickyStatus;
-    nine.spinLimit = vrdx::kSpinLimit;
-    nine.planWord = reinterpret_cast<uint32_t*>(storage + VRDX_OFF_PLAN);
-    nine.cap9 = cap9;
-    nine.top9Table = top9Table;
-    nine.slots = slots9;
-    EnqueueCheck(sorter, "scatter9_kernel", vrdx::LaunchScatter9(stream, tiles9, keyValue, nine));
-    vrdx::BucketSortArgs b;
-    b.keysScratch = keysScratch;
-    b.keysCaller = keys;
-    b.valuesScratch = keyValue ? valuesScratch : nullptr;
-    b.valuesCaller = keyValue ? values : nullptr;
-    b.maxCount = elementCount;
-    b.countPtr = countPtr;
-    b.histogramTable = globalHistogram;
-    b.hybridCap = cap9;
-    b.planWord = reinterpret_cast<const uint32_t*>(storage + VRDX_OFF_PLAN);
-    b.top9Table = top9Table;
-    EnqueueCheck(sorter, "bucket_sort_kernel (nine-bit)", vrdx::LaunchBucketSort9(stream, keyValue, b));
-  }
   // the arguments of pass `pass` of the four passes (also handed to the MSD plan's launches, whose second role they are)
   auto passArgs = [&](uint32_t pass) {
     vrdx::OnesweepArgs args;
@@ -590,8 +516,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     if (testSpinLimit >= 0) args.spinLimit = (uint32_t)testSpinLimit;
 #endif
     args.earlyValues = earlyValues ? 1u : 0u;
-    args.cap9 = cap9 != 0 ? cap9 : msdCap * (msdBits != 0 ? 1u : 0u);  // non-zero: a plan in front may have taken the sort (verdict 3)
-    args.top9Table = top9Table;
+    args.planInFront = msdBits != 0 ? 1u : 0u;  // the MSD plan in front may have taken the sort (verdict 3)
     args.slots = tilePlan.slots;
     args.fullTiles = tilePlan.fullTiles;
     args.tailSlots = tilePlan.tailSlots;
@@ -602,7 +527,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     return args;
   };
   uint32_t msdFused = 0;  // how many of the plan's launches double as the fallback's first passes (0 | 1: the scatter | 2: and the buckets)
-  // The MSD plan, recorded in front of the passes like the nine-bit plan: spine (prefixes over the tiles, bucket table,
+  // The MSD plan, recorded in front of the passes: spine (prefixes over the tiles, bucket table,
   // verdict), scatter by the top bits, one workgroup per bucket.  The passes behind return on the verdict word.
   if (msdBits != 0) {
     vrdx::MsdArgs m;
@@ -680,7 +605,6 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
       b.histogramTable = globalHistogram;
       b.hybridCap = hybridCap;
       b.planWord = reinterpret_cast<const uint32_t*>(storage + VRDX_OFF_PLAN);
-      b.top9Table = nullptr;
       EnqueueCheck(sorter, "bucket_sort_kernel", vrdx::LaunchBucketSort(stream, keyValue, atomicRank, b));
       Stamp(pool, query + 2 + 3 * pass + 0, stream);
     } else {
@@ -1032,8 +956,6 @@ void vrdxHipDescribePlan(VrdxSorter sorter, uint32_t elementCount, int keyValue,
   uint32_t msdCap = 0;
   const uint32_t hybridCap = adaptive ? HybridCapacity(atomicRank, elementCount) : 0u;
   const uint32_t msdBits = adaptive && hybridCap == 0 ? MsdBits(atomicRank, kv, elementCount, hybridCap, &msdCap) : 0u;
-  const uint32_t cap9 =
-      adaptive && msdBits == 0 ? Hybrid9Capacity(atomicRank, elementCount, hybridCap, (uint32_t)sorter->computeUnits) : 0u;
   if (msdBits != 0) {
     info->plan = VRDX_HIP_PLAN_MSD;
     info->bits = msdBits;
@@ -1041,11 +963,6 @@ void vrdxHipDescribePlan(VrdxSorter sorter, uint32_t elementCount, int keyValue,
     // histogram, spine, scatter, buckets, four returning passes (keys-only: two of them folded into the plan's launches,
     // one with the half-size bucket kernel)
     info->launches = kv ? 8u : (msdCap == vrdx::kMsdCapKeys ? 6u : 7u);
-  } else if (cap9 != 0) {
-    info->plan = VRDX_HIP_PLAN_HYBRID9;
-    info->bits = 9;
-    info->bytesPerElement = twoTrips;
-    info->launches = 7;
   } else if (hybridCap != 0) {
     info->plan = VRDX_HIP_PLAN_HYBRID8;
     info->bits = 8;

@@ -32,11 +32,6 @@ constexpr uint32_t kHistStreamingLoadsAbove = 1u << 25;  // histogram: keys (4 B
 constexpr uint32_t kStreamingLoadsAbove = 1u << 24;
 constexpr uint32_t kStreamingLoadsUpTo = 3u << 24;
 constexpr uint32_t HistLdsBytes(uint32_t copies) { return 4u * 256u * copies * 4u; }  // [pass][digit][copy]
-// the nine-bit form: three byte tables, then 512 bins x min(copies, kHistCopiesTop9) replicas
-constexpr uint32_t kHistCopiesTop9 = 16;
-constexpr uint32_t HistTop9LdsBytes(uint32_t copies) {
-  return (3u * 256u * copies + 512u * (copies < kHistCopiesTop9 ? copies : kHistCopiesTop9)) * 4u;
-}
 // keys one histogram workgroup counts per GROUP (kHistThreads lanes x four 16-byte loads x 4 keys); every wave keeps
 // two groups of loads in flight (vrdx_kernels.hip)
 constexpr uint32_t kHistGroupKeys = kHistThreads * 4 * 4;
@@ -88,11 +83,9 @@ struct OnesweepArgs {
   unsigned long long* trace;  // phase stamps, 8 per tile; nullptr outside tools/trace.sh builds
   uint32_t* planWord;         // hybridCap != 0: the verdict word in the storage (VRDX_OFF_PLAN), written by launch 0
                               // (last on purpose: the argument layout of the kernels that never read it stays as it was)
-  // The nine-bit hybrid plan (scatter9_kernel + bucket_sort_kernel<..., 512>), recorded for sorts beyond the eight-bit
-  // plan's reach: cap9 = 32768 and the 512 counts the histogram kernel left, or 0 / nullptr.  The passes only look at
-  // cap9 (return when the verdict word says 3); scatter9_kernel uses statusCur / ticketCur as ITS status region and ticket.
-  uint32_t cap9;
-  const uint32_t* top9Table;
+  // Non-zero: the MSD plan is recorded in front of the passes, which then return when the verdict word says 3 (the plan
+  // has taken the sort).
+  uint32_t planInFront;
 };
 
 // Raises the dynamic-LDS limit of both instantiations (keys-only, key-value) of one tile config.
@@ -100,15 +93,9 @@ hipError_t PrepareKernels(int configIndex);
 
 // Also zeroes the two tile tickets and status region 0 (statusClearBytes from statusClear, whole 1 KiB rows): they live
 // outside the prefix of the storage that the fill in front of this kernel clears.
-// top9Table != nullptr: the nine-bit form (512 counts of the keys' top nine bits there, their pair sums as row 3).
 hipError_t LaunchHistogram(hipStream_t stream, uint32_t grid, const uint32_t* keys, uint32_t maxCount,
                            const uint32_t* countPtr, uint32_t* globalHistogram, uint32_t* tickets, void* statusClear,
-                           uint32_t statusClearBytes, uint32_t* top9Table);
-
-// The nine-bit hybrid plan: scatter by the top nine bits (1024 threads x args.slots slots of 64 keys per wave, at most
-// kScatter9MaxSlots; grid = tiles of that many keys), then 512 sub-bucket sorts.
-constexpr uint32_t kScatter9MaxSlots = 32;
-hipError_t LaunchScatter9(hipStream_t stream, uint32_t grid, bool keyValue, const OnesweepArgs& args);
+                           uint32_t statusClearBytes);
 
 // atomicRank selects the one-LDS-atomic-per-key ranking; only legal when LdsOrderCheck() said so.
 hipError_t LaunchOnesweep(hipStream_t stream, int configIndex, uint32_t grid, bool keyValue, bool atomicRank,
@@ -134,11 +121,9 @@ struct BucketSortArgs {
   const uint32_t* histogramTable;  // uint[4][256]
   uint32_t hybridCap;              // elements one workgroup can take (selects the instantiation)
   const uint32_t* planWord;        // the verdict word in the storage (VRDX_OFF_PLAN), written by launch 0
-  const uint32_t* top9Table;       // nine-bit plan: the 512 counts (LaunchBucketSort9), otherwise unused
 };
 hipError_t PrepareBucketSort();
 hipError_t LaunchBucketSort(hipStream_t stream, bool keyValue, bool atomicRank, const BucketSortArgs& args);
-hipError_t LaunchBucketSort9(hipStream_t stream, bool keyValue, const BucketSortArgs& args);  // one-atomic ranking only
 
 // The MSD plan of large sorts (round 5; vrdx_kernels.hip, "MSD plan"): THREE ranking steps of 10-11 bits instead of four
 // of 8, and TWO trips of the data through memory instead of four --

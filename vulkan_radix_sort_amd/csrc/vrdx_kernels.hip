@@ -20,8 +20,10 @@
 //   * onesweep_pair_kernel -- the same pass with TWO 32768-key sub-tiles per workgroup, one ticket,
 //     one status row and one look-back for both (every keys-only sort beyond one "round" of tiles per CU,
 //     see ConfigIndex in vrdx_api.cpp).
-//   * small_sort_kernel / bucket_sort_kernel / scatter9_kernel -- sorts of up to 16384 elements in one workgroup;
-//     the two hybrid plans of mid-size sorts (one scatter by the top eight or nine bits, then every bucket in LDS).
+//   * small_sort_kernel / bucket_sort_kernel -- sorts of up to 16384 elements in one workgroup; the hybrid plan of
+//     mid-size sorts (one scatter by the highest varying byte, then every bucket in LDS).
+//   * histogram_msd_kernel / spine_msd_kernel / scatter_msd_kernel / bucket_sort2[_half]_kernel -- the MSD plan of sorts
+//     of 8.14 M ... 67 M elements: one chain-free scatter by the top 10-11 bits, then every bucket in LDS in two passes.
 //   Tile ids are handed out by an atomic ticket in ARRIVAL order, so a look-back only ever waits
 //   on a tile that is already running; every spin is bounded (failure word, never a hang).
 #include <hip/hip_runtime.h>
@@ -359,22 +361,6 @@ __device__ __forceinline__ uint32_t BlockExclusiveScan256(uint32_t v, uint32_t* 
   return x - v + add;
 }
 
-// The same over threads 0..511 (8 waves): the 512 sub-buckets of the nine-bit hybrid plan.
-__device__ __forceinline__ uint32_t BlockExclusiveScan512(uint32_t v, uint32_t* scratch8, int tid) {
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const uint32_t x = WaveInclusiveScan(v);
-  if (wave < 8 && lane == 63) scratch8[wave] = x;
-  LdsBarrier();
-  uint32_t add = 0;
-  if (wave < 8) {
-#pragma unroll
-    for (int w = 0; w < 7; ++w)
-      if (w < wave) add += scratch8[w];
-  }
-  return x - v + add;
-}
-
 // ---------------------------------------------------------------------------------------------
 // histogram: all four digit histograms in one pass over the keys
 // ---------------------------------------------------------------------------------------------
@@ -412,24 +398,18 @@ __device__ __forceinline__ void HistFetch(const u32x4* keys4, uint32_t group, ui
 // and the two tickets: nothing reads them before pass 0, which starts when this kernel has drained.  Before round 4
 // the fill in front of the histogram cleared region 0 as well -- 1-2 MiB at N = 2^25, a 4.4 us fill kernel on the
 // critical path of every sort where 4 KiB (header + table, which the atomics below need zeroed) take 2 us.
-// TOP9 (sorts that record the nine-bit hybrid plan, vrdx_api.cpp): instead of byte 3 the kernel counts the TOP NINE BITS
-// of the keys -- 512 bins x COPIES9 replicas behind the three byte tables, still four atomics per key -- and leaves
-// both the 512 counts (top9Table) and their pair sums, which are the byte-3 counts, in the global tables.
-template <uint32_t COPIES, bool TOP9>
+template <uint32_t COPIES>
 __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t* __restrict__ keys,
                                                                   uint32_t maxCount,
                                                                   const uint32_t* countPtr,
                                                                   uint32_t* __restrict__ globalHistogram,
                                                                   uint32_t* __restrict__ tickets,
                                                                   u32x4* __restrict__ statusClear,
-                                                                  uint32_t statusVecs,
-                                                                  uint32_t* __restrict__ top9Table) {
+                                                                  uint32_t statusVecs) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  uint32_t* const bins = smem;  // [pass][digit][copy] (TOP9: three passes, then [512][COPIES9])
-  constexpr uint32_t COPIES9 = COPIES < kHistCopiesTop9 ? COPIES : kHistCopiesTop9;
-  constexpr uint32_t kByteTables = TOP9 ? VRDX_PASSES - 1 : VRDX_PASSES;
-  constexpr uint32_t kBinWords = kByteTables * VRDX_RADIX * COPIES + (TOP9 ? 512u * COPIES9 : 0u);
-  uint32_t* const bins9 = smem + kByteTables * VRDX_RADIX * COPIES;
+  uint32_t* const bins = smem;  // [pass][digit][copy]
+  constexpr uint32_t kByteTables = VRDX_PASSES;
+  constexpr uint32_t kBinWords = kByteTables * VRDX_RADIX * COPIES;
   const uint32_t tid = threadIdx.x;
   if (blockIdx.x == 0 && tid < 3) tickets[tid] = 0;  // outside the cleared prefix of the storage (vrdx_layout.h)
   const uint32_t n = ElementCount(maxCount, countPtr);
@@ -441,7 +421,6 @@ __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t*
       const uint32_t d = (key >> (8 * p)) & 0xFFu;
       atomicAdd(&bins[(p * VRDX_RADIX + d) * COPIES + copy], 1u);
     }
-    if constexpr (TOP9) atomicAdd(&bins9[(key >> 23) * COPIES9 + (tid & (COPIES9 - 1))], 1u);
   };
   auto tally = [&](uint32_t group, const u32x4 (&k)[4], uint32_t nvec) {
 #pragma unroll
@@ -501,21 +480,6 @@ __global__ __launch_bounds__(kHistThreads) void histogram_kernel(const uint32_t*
 #pragma unroll
     for (uint32_t c = 0; c < COPIES; ++c) sum += bins[b * COPIES + ((c + tid) & (COPIES - 1))];
     if (sum != 0) atomicAdd(&globalHistogram[b], sum);
-  }
-  if constexpr (TOP9) {
-    static_assert(kHistThreads == 1024, "threads 768..1023 and 0..255 take the nine-bit bins");
-    // threads 768..1023 are free in the loop above (3 x 256 bins): they and threads 0..255 take the 512 nine-bit bins
-    const uint32_t b9 = tid >= 768u ? tid - 768u : (tid < 256u ? tid + 256u : 512u);
-    if (b9 < 512u) {
-      uint32_t sum = 0;
-#pragma unroll
-      for (uint32_t c = 0; c < COPIES9; ++c) sum += bins9[b9 * COPIES9 + ((c + tid) & (COPIES9 - 1))];
-      if (sum != 0) atomicAdd(&top9Table[b9], sum);
-      // byte 3 = the nine bits without the last: the pair sum, added by the even lane alone -- two lanes of ONE atomic
-      // instruction on the same address cost this kernel 57 us (77 instead of 21 at 12.6 M keys, measured)
-      const uint32_t pair = sum + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0xB1, 0xf, 0xf, true);  // quad_perm:[1,0,3,2]
-      if ((b9 & 1u) == 0 && pair != 0) atomicAdd(&globalHistogram[(VRDX_PASSES - 1) * VRDX_RADIX + (b9 >> 1)], pair);
-    }
   }
 }
 
@@ -589,7 +553,7 @@ __device__ __forceinline__ void StoreQuad(uint32_t* out, uint32_t index, u32x4 q
   }
 }
 
-// RADIX: digits per status row (256; 512 in the nine-bit scatter: two groups of 512 threads then).
+// RADIX: digits per status row (256 in every kernel built today; THREADS / RADIX groups of threads share the look-back).
 template <int THREADS, int RADIX = 256, int W = kLookBackWindow>
 __device__ __forceinline__ uint32_t LookBack(const uint32_t* status, uint32_t tile, int tid, uint32_t* lds,
                                              uint32_t* failure, uint32_t* stickyFailure, uint32_t spinLimit,
@@ -801,7 +765,7 @@ __device__ __forceinline__ void RankBallot(const uint32_t (&key)[KPT], uint32_t 
 }
 
 // PACKED: ranks (< 64 * KPT <= 65536) are written two to a register, out[i / 2] bits 16*(i % 2).
-// MASK: the digit is (key >> shift) & MASK -- 0xFF everywhere except the 512-way scatter of the nine-bit hybrid plan.
+// MASK: the digit is (key >> shift) & MASK -- 0xFF in every kernel built today.
 template <int KPT, bool PACKED, bool DYN = false, uint32_t MASK = 0xFFu>
 __device__ __forceinline__ void RankAtomic(const uint32_t (&key)[KPT], uint32_t shift, uint32_t* myHist,
                                            int lane, uint32_t (&out)[PACKED ? KPT / 2 : KPT], uint32_t slots = KPT) {
@@ -1139,8 +1103,8 @@ __device__ __forceinline__ void OnesweepBody(const OnesweepArgs a) {
   if constexpr (kVerdictWord) {
     if (a.hybridCap != 0 && a.pass != 0 && *a.planWord == 1u) return;
   }
-  // the nine-bit plan (scatter9_kernel, recorded in front of launch 0) has taken the sort: nothing left for the passes
-  if (a.cap9 != 0 && *a.planWord == 3u) return;
+  // the MSD plan (recorded in front of launch 0) has taken the sort: nothing left for the passes
+  if (a.planInFront != 0 && *a.planWord == 3u) return;
 
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   uint32_t key[KPT];
@@ -1399,7 +1363,7 @@ __device__ __forceinline__ void OnesweepPairBody(const OnesweepArgs a) {
 #endif
   VRDX_STAMP(0);
 
-  if (a.cap9 != 0 && *a.planWord == 3u) return;  // the nine-bit plan has taken the sort (see onesweep_kernel)
+  if (a.planInFront != 0 && *a.planWord == 3u) return;  // the MSD plan has taken the sort (see onesweep_kernel)
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   const PassCounts<THREADS> passCounts = LoadPassCounts<THREADS>(a.histogramTable, tid);
   if (tid == 0) misc[0] = (VRDX_ABLATE & 8) ? blockIdx.x : atomicAdd(a.ticketCur, 1u);
@@ -1581,201 +1545,6 @@ __device__ __forceinline__ void OnesweepPairBody(const OnesweepArgs a) {
 template <int THREADS, int KPT, bool DYN>
 __global__ __launch_bounds__(THREADS, (PairMinWavesPerSimd<THREADS, KPT>())) void onesweep_pair_kernel(OnesweepArgs a) {
   OnesweepPairBody<THREADS, KPT, DYN>(a);
-}
-
-// ---------------------------------------------------------------------------------------------
-// scatter9_kernel: first half of the NINE-BIT hybrid plan -- one stable scatter by the top nine bits
-// ---------------------------------------------------------------------------------------------
-// The hybrid plan of mid-size sorts (PassPlan above) ends where a bucket of the top BYTE no longer fits one workgroup's
-// LDS: 256 x 32768 elements.  Twice as many buckets carry it twice as far: this kernel scatters by the top NINE bits
-// (512 sub-buckets; caller -> scratch), bucket_sort_kernel<..., 512> then sorts every sub-bucket by its low 24 bits inside
-// one workgroup (scratch -> caller), and the ordinary launches 0..3 of the sort return on the verdict word.  The plan
-// applies iff no nine-bit value occurs more than a.cap9 (= 32768) times -- every workgroup decides that alike from the
-// 512 counts the histogram kernel left in a.top9Table; otherwise this launch returns without touching anything and the
-// sort runs its four passes as if the plan had never been recorded.
-//
-// It is onesweep_kernel with 512 digits, written out: 1024 threads x up to 32 keys (a.slots slots of 64 keys per wave,
-// a multiple of four: the host cuts the sort into equal tiles, two rounds of them, Scatter9Slots in vrdx_api.cpp),
-// wave-private counters 16 x 512 words, one status row of 512 words per tile in a status region of its own, look-back by
-// two groups of 512 threads.  One-atomic ranking only (like the 32768-element buckets).
-// LDS: staging 128 KiB | counters 32 KiB = exactly the CU's 160 KiB: scan scratch, ticket and verdict flags live in the
-// staging buffer before the regroup, look-back scratch and the 512 scatter offsets in the counters after it.
-// (First version: tiles of 16384 keys, 96 KiB: 49.6 us at 12.6 M keys against 28.8 us for a pass of the two-sub-tile
-// kernel, which ate the plan's gain for keys-only sorts; profiles/r04_nine_bit_plan.txt.)
-constexpr int kScatter9Threads = 1024;
-constexpr int kScatter9Kpt = 32;
-constexpr uint32_t kScatter9Tile = kScatter9Threads * kScatter9Kpt;
-constexpr uint32_t kTop9 = 512;
-constexpr uint32_t kTop9Shift = 23;
-constexpr size_t kScatter9LdsWords = (size_t)kScatter9Tile + (size_t)(kScatter9Threads / 64) * kTop9;
-#ifndef VRDX_SCATTER9_WINDOW
-#define VRDX_SCATTER9_WINDOW 16
-#endif
-constexpr int kScatter9Window = VRDX_SCATTER9_WINDOW;  // rows per thread and look-back trip: two groups of 512 threads cover 2 x 16 tiles
-static_assert(kScatter9LdsWords * 4 <= 160 * 1024, "fits the CU's LDS");
-
-template <bool KV>
-__global__ __launch_bounds__(kScatter9Threads) void scatter9_kernel(OnesweepArgs a) {
-  constexpr int THREADS = kScatter9Threads;
-  constexpr int KPT = kScatter9Kpt;
-  constexpr int WAVES = THREADS / 64;
-  constexpr uint32_t TILE = kScatter9Tile;
-  constexpr uint32_t MASK = kTop9 - 1;
-  constexpr bool DYN = true;
-  static_assert(WAVES * kTop9 >= kTop9 * (1 + 2 * (THREADS / kTop9)) + 2 + kTop9, "look-back scratch and offsets alias the counters");
-
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  uint32_t* const sorted = smem;                               // TILE: keys (then values) regrouped by digit
-  uint32_t* const waveHist = smem + TILE;                      // WAVES x 512, then look-back scratch
-  uint32_t* const tileOffset = waveHist + (WAVES - 1) * kTop9;  // 512: global base - tile-local base (after the regroup)
-  uint32_t* const scanScratch = smem;                          // 16 (before the regroup)
-  uint32_t* const misc = smem + 16;                            // [0] ticket, [1..16] "over capacity" by wave
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-
-  // the verdict, the same in every workgroup: does any nine-bit value occur more than cap9 times?
-  // (The ticket is drawn at once, together with the loads of the 512 counts -- one global round trip on the tile's
-  // critical path instead of two; it is this launch's own ticket word, so drawing one for nothing does no harm.)
-  const uint32_t n = ElementCount(a.maxCount, a.countPtr);
-  const uint32_t bucketCount = tid < (int)kTop9 ? a.top9Table[tid] : 0u;
-  if (tid == 0) misc[0] = atomicAdd(a.ticketCur, 1u);
-  const uint64_t over = __ballot(bucketCount > a.cap9);
-  if (lane == 0) misc[1 + wave] = over != 0ull ? 1u : 0u;
-  for (int i = tid; i < WAVES * (int)kTop9; i += THREADS) waveHist[i] = 0;
-  LdsBarrier();
-  uint32_t anyOver = 0;
-#pragma unroll
-  for (int w = 0; w < WAVES; ++w) anyOver |= misc[1 + w];
-  if (anyOver != 0 || n == 0) return;  // uniform: the plan does not apply, the four passes run
-  const uint32_t tile = misc[0];
-  if (tile == 0 && tid == 0) *a.planWord = 3u;  // for the launches behind this one: nothing left to do but the buckets
-  const uint32_t slots = a.slots;               // per wave, a multiple of four, <= KPT
-  const uint32_t frame = slots * THREADS;
-  const uint32_t tiles = (n + frame - 1) / frame;
-  if (tile >= tiles) return;
-  const bool lastTile = tile == tiles - 1;
-  const uint32_t tileStart = tile * frame;
-  const uint32_t valid = (n - tileStart) < frame ? (n - tileStart) : frame;
-  const uint32_t tileEnd = tileStart + valid;
-  const uint32_t loadBase = tileStart + wave * (slots * 64) + lane;
-
-  uint32_t key[KPT];
-  uint32_t val[KV ? KPT : 1];
-  LoadStriped<KPT, false, DYN>(a.keysCaller, loadBase, tileEnd, valid == frame, 0xFFFFFFFFu, key, slots);  // pad: downsweep.slang:81
-  constexpr bool PACKED = true;  // ranks and positions < TILE <= 65536, two to a register
-  uint32_t rank[KPT / 2];
-  RankAtomic<KPT, PACKED, DYN, MASK>(key, kTop9Shift, waveHist + wave * kTop9, lane, rank, slots);
-  ForgetDerivedValues<KPT>(key);
-  LdsBarrier();
-
-  // tile histogram, aggregate, tile-local offsets
-  uint32_t count = 0;
-  if (tid < (int)kTop9) {
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) count += waveHist[w * kTop9 + tid];
-    if (tile != 0 && !lastTile)
-      StoreStatus(&a.statusCur[tile * kTop9 + tid], (VRDX_FLAG_AGGREGATE << VRDX_FLAG_SHIFT) | count);
-  }
-  const uint32_t tileExclusive = BlockExclusiveScan512(tid < (int)kTop9 ? count : 0u, scanScratch, tid);
-  uint32_t exclusive = 0;
-  if (tile == 0) exclusive = BlockExclusiveScan512(bucketCount, scanScratch + 8, tid);  // the global base of every sub-bucket
-  if (tid < (int)kTop9) {
-    uint32_t run = tileExclusive;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) {
-      const uint32_t c = waveHist[w * kTop9 + tid];
-      waveHist[w * kTop9 + tid] = run;
-      run += c;
-    }
-  }
-  LdsBarrier();
-
-  uint32_t packedPos[KV ? KPT / 2 : 1];
-  RegroupKeys<KPT, TILE, PACKED, KV, DYN, MASK>(key, rank, kTop9Shift, waveHist + wave * kTop9, sorted, packedPos, slots);
-  LdsBarrier();  // waveHist is dead from here on
-
-  if (tile != 0)
-    exclusive = LookBack<THREADS, (int)kTop9, kScatter9Window>(a.statusCur, tile, tid, waveHist, a.failure, a.stickyFailure,
-                                                               a.spinLimit, nullptr);
-  if (tid < (int)kTop9) {
-    if (!lastTile)
-      StoreStatus(&a.statusCur[tile * kTop9 + tid],
-                  (VRDX_FLAG_INCLUSIVE << VRDX_FLAG_SHIFT) | ((exclusive + count) & VRDX_VALUE_MASK));
-    tileOffset[tid] = exclusive - tileExclusive;
-  }
-  LdsBarrier();
-  // key+value: the values are fetched now (late, like the split forms of onesweep_kernel: early they would be live across
-  // the ranking and the regroup of 32 keys per lane) and land while the keys are scattered
-  if constexpr (KV) LoadStriped<KPT, false, DYN>(a.valuesCaller, loadBase, tileEnd, valid == frame, 0u, val, slots);  // pad: downsweep.slang:85
-
-  // scatter: four consecutive staging words per lane.  The main loop stores ONLY whole single-digit quads (one 16-byte
-  // store each, four quads per batch: reads, then digits and offsets, then stores); the quads that straddle a run boundary
-  // -- one in twelve with 48-key runs, but some lane of nearly every wave instruction has one, and a wave walks through
-  // every branch any of its lanes takes -- are stored afterwards, word by word, by the thread that knows where they are:
-  // thread d holds the tile-local start of digit d's run (ScatterStagedKeys of the pass kernels does the same).
-  constexpr int QUADS = KPT / 4;
-  constexpr int B = 4;
-  uint32_t quadDigits[KV ? QUADS : 1];  // key+value: first | last << 16 digit of every main-loop quad, for the value phase
-  uint32_t boundaryDigits[2] = {0, 0};  // the four digits of this thread's boundary quad
-  uint32_t boundaryQuad = ~0u;
-  if (tid < (int)kTop9 && count != 0 && (tileExclusive & 3u) != 0 && tileExclusive < valid) boundaryQuad = tileExclusive & ~3u;
-  if (tid == 0 && (valid & 3u) != 0) boundaryQuad = valid & ~3u;
-  auto scatterQuads = [&](uint32_t* out, bool keysPhase) {
-#pragma unroll
-    for (int j0 = 0; j0 < QUADS; j0 += B) {
-      if (4u * (uint32_t)j0 * THREADS >= valid) break;  // batches of quads beyond the tile's keys are not read at all
-      u32x4 w4[B];
-      uint32_t o[B];
-      bool whole[B];
-#pragma unroll
-      for (int b = 0; b < B; ++b) w4[b] = *reinterpret_cast<const u32x4*>(&sorted[4u * (tid + (j0 + b) * THREADS)]);
-#pragma unroll
-      for (int b = 0; b < B; ++b) {
-        const int j = j0 + b;
-        const uint32_t p = StagingSlot<TILE>(4u * (tid + j * THREADS));  // involution: the sorted position of the quad
-        uint32_t d0, d3;
-        if (keysPhase) {
-          d0 = (w4[b][0] >> kTop9Shift) & MASK;
-          d3 = (w4[b][3] >> kTop9Shift) & MASK;
-          if constexpr (KV) quadDigits[j] = d0 | (d3 << 16);
-        } else {
-          d0 = quadDigits[KV ? j : 0] & 0xFFFFu;
-          d3 = quadDigits[KV ? j : 0] >> 16;
-        }
-        whole[b] = p + 3 < valid && d0 == d3;
-        o[b] = tileOffset[d0] + p;
-        asm volatile("" : "+v"(o[b]));  // fetched here, for every quad: not sunk into the conditional store
-      }
-#pragma unroll
-      for (int b = 0; b < B; ++b)
-        if (whole[b]) StoreQuad(out, o[b], w4[b]);
-    }
-    if (boundaryQuad != ~0u) {
-      const u32x4 q = *reinterpret_cast<const u32x4*>(&sorted[StagingSlot<TILE>(boundaryQuad)]);
-      if (keysPhase) {
-        boundaryDigits[0] = ((q[0] >> kTop9Shift) & MASK) | (((q[1] >> kTop9Shift) & MASK) << 16);
-        boundaryDigits[1] = ((q[2] >> kTop9Shift) & MASK) | (((q[3] >> kTop9Shift) & MASK) << 16);
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const uint32_t d = (boundaryDigits[c / 2] >> (16 * (c % 2))) & 0xFFFFu;
-        if (boundaryQuad + c < valid) StoreWord(out, tileOffset[d] + boundaryQuad + c, q[c]);
-      }
-    }
-  };
-  scatterQuads(a.keysScratch, true);
-  if constexpr (KV) {
-    LdsBarrier();  // every key has left the staging buffer
-#pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-      if (i % 4 == 0 && (uint32_t)i >= slots) break;
-      sorted[(packedPos[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = val[i];
-    }
-    LdsBarrier();
-    scatterQuads(a.valuesScratch, false);
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1972,35 +1741,13 @@ __global__ __launch_bounds__(THREADS) void small_sort_kernel(uint32_t* keys, uin
 // derives, from the same table as the pass kernels, whether the hybrid plan applies at all; otherwise this launch has
 // nothing to do (the four-pass plan is running).
 
-// NB = 512: the second half of the NINE-BIT plan (scatter9_kernel above) -- bucket b is the range of the nine-bit value b,
-// counts from a.top9Table; it runs iff scatter9_kernel has written 3 into the verdict word.
-template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK, int NB = 256>
+template <int THREADS, int KPT, bool KV, bool ATOMIC_RANK>
 __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(BucketSortArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int tid = threadIdx.x;
-  if constexpr (NB == 512) {
-    static_assert(THREADS >= 512, "one thread per sub-bucket");
-    if (*a.planWord != 3u) return;  // uniform: the nine-bit plan does not apply (or was not reached)
-    const uint32_t count = tid < 512 ? a.top9Table[tid] : 0u;
-    const uint32_t base = BlockExclusiveScan512(count, smem, tid);
-    if (tid == (int)blockIdx.x) {
-      smem[16] = base;
-      smem[17] = count;
-    }
-    LdsBarrier();
-    const uint32_t myBase = (uint32_t)__builtin_amdgcn_readfirstlane((int)smem[16]);
-    const uint32_t myCount = (uint32_t)__builtin_amdgcn_readfirstlane((int)smem[17]);
-    LdsBarrier();  // smem is the sort's from here on
-    if (myCount == 0) return;  // uniform
-    // by the low 24 bits: bit 23 is the same in every key of the sub-bucket
-    SortInWorkgroup<THREADS, KPT, KV, ATOMIC_RANK>(a.keysScratch + myBase, a.keysCaller + myBase,
-                                                   KV ? a.valuesScratch + myBase : nullptr,
-                                                   KV ? a.valuesCaller + myBase : nullptr, myCount, 3u, smem);
-    return;
-  }
   uint32_t* const flags = smem + 16;  // 32
   const uint32_t verdict = *a.planWord;
-  if (verdict == 2u || verdict == 3u) return;  // launch 0's verdict: the four passes are running / the nine-bit plan has run
+  if (verdict == 2u || verdict == 3u) return;  // launch 0's verdict: the four passes are running
   // the same votes, from the same table, as in the pass kernels: every launch of the sort reaches the same verdict
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   const PassCounts<THREADS> passCounts = LoadPassCounts<THREADS>(a.histogramTable, tid);
@@ -2540,7 +2287,7 @@ __device__ __forceinline__ void ScatterMsdBody(const MsdArgs a) {
     sorted[(rank[i / 2] >> (16 * (i % 2))) & 0xFFFFu] = key[i];
   }
   LdsBarrier();
-  // key+value: the values are fetched now and land while the keys are scattered (like scatter9_kernel)
+  // key+value: the values are fetched now and land while the keys are scattered (like the pass kernels' early value fetch)
   uint32_t val[KV ? KPT : 1];
   if constexpr (KV)
     LoadStriped<KPT, VRDX_MSD_NT_LOADS != 0, DYN>(a.valuesCaller, loadBase, tileEnd, valid == frame, 0u, val, slots);  // pad: downsweep.slang:85
@@ -3068,13 +2815,9 @@ hipError_t PrepareKernels(int configIndex) {
     const struct {
       const void* fn;
       uint32_t bytes;
-    } kernels[6] = {
-        {reinterpret_cast<const void*>(&histogram_kernel<kHistCopies, false>), HistLdsBytes(kHistCopies)},
-        {reinterpret_cast<const void*>(&histogram_kernel<kHistCopiesLarge, false>), HistLdsBytes(kHistCopiesLarge)},
-        {reinterpret_cast<const void*>(&histogram_kernel<kHistCopies, true>), HistTop9LdsBytes(kHistCopies)},
-        {reinterpret_cast<const void*>(&histogram_kernel<kHistCopiesLarge, true>), HistTop9LdsBytes(kHistCopiesLarge)},
-        {reinterpret_cast<const void*>(&scatter9_kernel<false>), (uint32_t)(kScatter9LdsWords * sizeof(uint32_t))},
-        {reinterpret_cast<const void*>(&scatter9_kernel<true>), (uint32_t)(kScatter9LdsWords * sizeof(uint32_t))},
+    } kernels[2] = {
+        {reinterpret_cast<const void*>(&histogram_kernel<kHistCopies>), HistLdsBytes(kHistCopies)},
+        {reinterpret_cast<const void*>(&histogram_kernel<kHistCopiesLarge>), HistLdsBytes(kHistCopiesLarge)},
     };
     for (const auto& k : kernels) {
       const hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.bytes);
@@ -3209,13 +2952,6 @@ hipError_t PrepareBucketSort() {
   if (e == hipSuccess)
     e = hipFuncSetAttribute(BucketKernel<32, true, true>(), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(SmallSortLdsWords<1024, 32, true>() * 4));
-  // the nine-bit plan's 512 sub-buckets (same capacity, same ranking)
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_sort_kernel<1024, 32, false, true, 512>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SmallSortLdsWords<1024, 32, false>() * 4));
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_sort_kernel<1024, 32, true, true, 512>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SmallSortLdsWords<1024, 32, true>() * 4));
   return e;
 }
 
@@ -3235,36 +2971,14 @@ hipError_t LaunchBucketSort(hipStream_t stream, bool keyValue, bool atomicRank, 
 
 hipError_t LaunchHistogram(hipStream_t stream, uint32_t grid, const uint32_t* keys, uint32_t maxCount,
                            const uint32_t* countPtr, uint32_t* globalHistogram, uint32_t* tickets, void* statusClear,
-                           uint32_t statusClearBytes, uint32_t* top9Table) {
+                           uint32_t statusClearBytes) {
   u32x4* const clear = reinterpret_cast<u32x4*>(statusClear);
   const uint32_t vecs = statusClearBytes / 16u;  // whole status rows: a multiple of 1 KiB, 128-byte aligned
   const bool many = maxCount >= kHistManyCopiesFrom;
-  const void* kernel;
-  uint32_t lds;
-  if (top9Table != nullptr) {  // the nine-bit plan is recorded: the top nine bits instead of byte 3
-    kernel = many ? reinterpret_cast<const void*>(&histogram_kernel<kHistCopiesLarge, true>)
-                  : reinterpret_cast<const void*>(&histogram_kernel<kHistCopies, true>);
-    lds = HistTop9LdsBytes(many ? kHistCopiesLarge : kHistCopies);
-  } else {
-    kernel = many ? reinterpret_cast<const void*>(&histogram_kernel<kHistCopiesLarge, false>)
-                  : reinterpret_cast<const void*>(&histogram_kernel<kHistCopies, false>);
-    lds = HistLdsBytes(many ? kHistCopiesLarge : kHistCopies);
-  }
-  return Launch(kernel, grid, kHistThreads, lds, stream, keys, maxCount, countPtr, globalHistogram, tickets, clear, vecs,
-                top9Table);
-}
-
-hipError_t LaunchScatter9(hipStream_t stream, uint32_t grid, bool keyValue, const OnesweepArgs& args) {
-  const void* const kernel = keyValue ? reinterpret_cast<const void*>(&scatter9_kernel<true>)
-                                      : reinterpret_cast<const void*>(&scatter9_kernel<false>);
-  return Launch(kernel, grid, kScatter9Threads, kScatter9LdsWords * sizeof(uint32_t), stream, args);
-}
-
-hipError_t LaunchBucketSort9(hipStream_t stream, bool keyValue, const BucketSortArgs& args) {
-  const size_t lds = (keyValue ? SmallSortLdsWords<1024, 32, true>() : SmallSortLdsWords<1024, 32, false>()) * 4;
-  const void* const kernel = keyValue ? reinterpret_cast<const void*>(&bucket_sort_kernel<1024, 32, true, true, 512>)
-                                      : reinterpret_cast<const void*>(&bucket_sort_kernel<1024, 32, false, true, 512>);
-  return Launch(kernel, 512, 1024, lds, stream, args);
+  const void* const kernel = many ? reinterpret_cast<const void*>(&histogram_kernel<kHistCopiesLarge>)
+                                  : reinterpret_cast<const void*>(&histogram_kernel<kHistCopies>);
+  return Launch(kernel, grid, kHistThreads, HistLdsBytes(many ? kHistCopiesLarge : kHistCopies), stream, keys, maxCount, countPtr,
+                globalHistogram, tickets, clear, vecs);
 }
 
 // ---- MSD plan -----------------------------------------------------------------------------------------

@@ -97,18 +97,15 @@ struct StorageLayout {
   uint64_t ticketOffset;     // uint32[2], zeroed by the histogram kernel
   uint64_t failureOffset;    // uint32
   uint64_t histogramOffset;  // uint32[4][256]
-  uint64_t top9Offset;       // uint32[512]: counts of the keys' top nine bits (nine-bit hybrid plan only), behind the table
-  uint64_t status9Offset;    // uint32[tiles9 - 1][512]: status rows of scatter9_kernel (nine-bit hybrid plan only)
-  uint64_t status9Bytes;
   uint64_t msdCountsOffset;  // MSD plan only: uint16[msdTiles][2^msdBits] per-tile counts / prefixes of the keys' top bits,
-  uint64_t msdCountsBytes;   //   in front of status region 0 like the nine-bit plan's rows (the two plans exclude each other)
+  uint64_t msdCountsBytes;   //   on the first 128-byte line behind the table, in front of status region 0
   uint64_t msdBucketOffset;  // MSD plan only: uint32[2][2^msdBits] bucket bases, then bucket sizes
   uint64_t statusOffset;     // uint32[2][rows + blockRows][256]: tile rows, then block rows, per region
   uint64_t statusRows;       // tile rows per region = max(tiles - 1, 0)
   uint64_t blockRows;        // block-sum rows per region (one per 32 tiles); 0 = classic look-back
   uint64_t regionBytes;      // (statusRows + blockRows) KiB
   uint64_t clearBytes;       // bytes from storageOffset zeroed by the fill in front of every sort: header + global histogram
-  uint64_t statusClearOffset; // what the histogram kernel zeroes: the nine-bit plan's rows (if any) and status region 0
+  uint64_t statusClearOffset; // what the histogram kernel (MSD plan: the spine kernel) zeroes: status region 0
   uint64_t statusClearBytes;  // (pass 0 is its first reader)
   uint64_t inoutOffset;      // keys scratch
   uint64_t valuesOffset;     // values scratch (KV only)
@@ -119,13 +116,10 @@ struct StorageLayout {
 // tiles: status rows are sized for this many tiles (PlanTiles); storageAddress: the absolute address of the storage
 // (buffer + storageOffset) -- only its low 7 bits matter; the sizes do not depend on it.
 // blockSums: the sort uses block sums (PlanTiles said so): one more row per 32 tiles in each status region.
-// tiles9: tiles of scatter9_kernel when the nine-bit hybrid plan is recorded next to the passes (0: it is not): the 512
-// nine-bit counts follow the histogram table (one fill clears both) and that launch's status rows, 2 KiB each, sit in
-// front of status region 0 (the histogram kernel clears both in one sweep).
 // msdBits / msdTiles: the MSD plan is recorded in front of the passes (10 | 11 bits, tiles of 32768 keys; 0: it is not).
 static inline StorageLayout MakeLayout(uint32_t maxElementCount, uint32_t align, uint64_t tiles,
-                                       uint64_t storageAddress = 0, bool blockSums = false, uint64_t tiles9 = 0,
-                                       uint32_t msdBits = 0, uint64_t msdTiles = 0) {
+                                       uint64_t storageAddress = 0, bool blockSums = false, uint32_t msdBits = 0,
+                                       uint64_t msdTiles = 0) {
   StorageLayout l;
   const uint64_t elementCountSize = Align((uint32_t)sizeof(uint32_t), align);
   const uint64_t histogramSize = HistogramSize(maxElementCount, align);
@@ -133,11 +127,8 @@ static inline StorageLayout MakeLayout(uint32_t maxElementCount, uint32_t align,
   l.countOffset = VRDX_OFF_COUNT;
   l.failureOffset = VRDX_OFF_FAILURE;
   l.histogramOffset = elementCountSize;
-  l.top9Offset = l.histogramOffset + VRDX_PASSES * VRDX_RADIX * sizeof(uint32_t);
-  const uint64_t tableEnd = l.top9Offset + (tiles9 != 0 ? 512 * sizeof(uint32_t) : 0);
-  l.status9Offset = tableEnd + ((0 - (storageAddress + tableEnd)) & 127u);
-  l.status9Bytes = tiles9 > 1 ? (tiles9 - 1) * 512 * sizeof(uint32_t) : 0;
-  l.msdCountsOffset = l.status9Offset + l.status9Bytes;
+  const uint64_t tableEnd = l.histogramOffset + VRDX_PASSES * VRDX_RADIX * sizeof(uint32_t);
+  l.msdCountsOffset = tableEnd + ((0 - (storageAddress + tableEnd)) & 127u);  // the first 128-byte line behind the table
   l.msdCountsBytes = msdBits != 0 ? msdTiles * ((uint64_t)2 << msdBits) : 0;  // 16 bits per (tile, bucket)
   l.msdBucketOffset = l.msdCountsOffset + l.msdCountsBytes;
   l.statusOffset = l.msdBucketOffset + (msdBits != 0 ? ((uint64_t)8 << msdBits) : 0);  // (a multiple of 128 bytes like the rest)
@@ -147,8 +138,8 @@ static inline StorageLayout MakeLayout(uint32_t maxElementCount, uint32_t align,
   // count + plan word + failure word + global histogram: what the histogram kernel's atomics and the passes' first
   // reads need zeroed BEFORE that kernel starts; status region 0 is zeroed by the histogram kernel itself
   l.clearBytes = tableEnd;
-  l.statusClearOffset = tiles9 != 0 ? l.status9Offset : l.statusOffset;
-  l.statusClearBytes = l.status9Bytes + l.regionBytes;
+  l.statusClearOffset = l.statusOffset;
+  l.statusClearBytes = l.regionBytes;
   l.ticketOffset = l.statusOffset + 2 * l.regionBytes;
   l.inoutOffset = l.ticketOffset + 128;
   l.valuesOffset = l.inoutOffset + (((uint64_t)maxElementCount * sizeof(uint32_t) + 127u) & ~(uint64_t)127u);
@@ -164,14 +155,6 @@ static inline StorageLayout MakeLayout(uint32_t maxElementCount, uint32_t align,
 static inline bool LayoutFits(const StorageLayout& l, uint32_t maxElementCount) {
   const uint64_t bytes = (uint64_t)maxElementCount * sizeof(uint32_t);
   return l.inoutOffset + bytes <= l.keysOnlySize && l.valuesOffset + bytes <= l.keyValueSize;
-}
-
-// The nine-bit hybrid plan's scatter (scatter9_kernel) cuts the sort into equal tiles, two rounds of them on `cus` CUs:
-// slots of 64 keys per wave of its 1024 threads (a multiple of four, 8 ... 32).  Its status rows are 2 KiB per tile.
-static inline uint32_t Scatter9Slots(uint32_t elementCount, uint32_t cus) {
-  uint32_t slots = 4u * RoundUp(RoundUp(elementCount, 2u * cus), 4096u);
-  if (slots < 8u) slots = 8u;
-  return slots > 32u ? 32u : slots;
 }
 
 // The MSD plan's scatter (scatter_msd_kernel, one workgroup per CU and tile) cuts the sort into EQUAL tiles that fill whole
