@@ -2533,8 +2533,10 @@ __global__ __launch_bounds__(1024) void bucket_sort2_kernel(MsdArgs a) {
 // 72 KiB of LDS, TWO to a CU -- one loads or scans while the other ranks.  A bucket has a fixed cost of 5.7 us in the
 // kernel above (load latency, two column scans, eight barriers), half the time of a bucket of 8192 keys, and with one
 // workgroup per CU nothing runs beside it.
+// (__launch_bounds__' second argument is WAVES PER SIMD here: two workgroups of eight waves on four SIMDs = 4, i.e. at most
+// 128 registers; the kernels take 85 keys-only and 121 key+value.)
 template <uint32_t BITS, bool KV>
-__global__ __launch_bounds__(512, 2) void bucket_sort2_half_kernel(MsdArgs a) {
+__global__ __launch_bounds__(512, 4) void bucket_sort2_half_kernel(MsdArgs a) {
   BucketSort2Body<BITS, kMsdHalfCap / 512, KV, 512>(a);
 }
 
