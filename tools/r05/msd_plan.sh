@@ -1,5 +1,5 @@
 #!/bin/bash
-# NOTE: profiles/r05_msd_plan.txt was produced by this script on the tree tagged before-nine-bit-removal, where VRDX_MSD=0 still
+# NOTE: profiles/r05_msd_plan.txt was produced by this script on the tree of commit ea48965 (before the nine-bit plan was removed), where VRDX_MSD=0 still
 # recorded round 4's nine-bit hybrid plan up to 16.2 M elements; on later trees VRDX_MSD=0 gives the four passes at every size and
 # the "nine bits" block of part (2) shows only the pass kernels.
 # profiles/r05_msd_plan.txt: (1) 20 sizes from 2^23 to 2^26, keys-only and key+value, reference protocol, with the per-stage
