@@ -277,7 +277,7 @@ int Parity(Harness& h, bool quick) {
     sizes.push_back((1u << 23) + (1u << 21) + 77);
     sizes.push_back((1u << 24) + 70001);
     sizes.push_back(3u * (1u << 23) + 200003);
-    // 8.1 M < N <= 18.3 M: the MSD plan with the half-size bucket kernel; the sizes above from 2^23 + 4097 to 2^24 take it
+    // 8.1 M < N <= 18.1 M: the MSD plan with the half-size bucket kernel; the sizes above from 2^23 + 4097 to 2^24 take it
     sizes.push_back(16200000);
   }
   for (uint32_t n : sizes) {
@@ -374,7 +374,7 @@ int MsdParity(Harness& h, const std::vector<uint32_t>& wanted) {
     std::fflush(stdout);
   };
   std::vector<uint32_t> sizes = wanted;
-  if (sizes.empty()) sizes = {8144129u, 18325504u, 18325505u, 20000003u, 1u << 25, 36000001u, 45000000u};
+  if (sizes.empty()) sizes = {8144129u, 18149376u, 18149377u, 20000003u, 1u << 25, 36000001u, 45000000u};
   for (uint32_t n : sizes) {
     std::vector<uint32_t> v;
     auto k = Mt(n, 1, 32, &v);

@@ -89,13 +89,13 @@ def check_against_oracle(torch, sorter, oracle, keys, values=None, **kw):
 
 MSD_FROM = 8_150_000        # vrdx_api.cpp MsdBits: sorts past the end of the eight-bit plan (8.1 M) record the MSD plan in front of the passes
 MSD_FROM_KEYS = MSD_FROM    # (keys-only and key+value alike since the half-size bucket kernel)
-MSD_HALF_UP_TO = 18_325_504  # ... with buckets of at most 18432 (512-thread bucket kernel) while ceil(n / 1024) * 103 // 100 <= 18432
+MSD_HALF_UP_TO = 18_149_376  # ... with buckets of at most 18432 (512-thread bucket kernel) while ceil(n / 1024) * 104 // 100 <= 18432
 
 
 def msd_capacity(n, bits):
     """the bucket capacity the recorder checks on the device (MsdBits: 3 % headroom over the mean bucket)"""
     mean = -(-n // (1 << bits))
-    return 18432 if bits == 10 and mean * 103 // 100 <= 18432 else 36864
+    return 18432 if bits == 10 and mean * 104 // 100 <= 18432 else 36864
 
 
 def decline_msd(keys):
@@ -600,7 +600,7 @@ def test_msd_plan_and_its_fallback_at_the_bucket_capacity(torch_mod, sorter, ora
     """Sorts of 8.15 M elements and more record the MSD plan in front of their four passes (vrdx_kernels.hip, "MSD plan"):
     per-tile counts of the top ten or eleven bits, a spine, ONE stable scatter by those bits and one workgroup per bucket
     that sorts it by the remaining bits in two in-LDS passes; the DEVICE keeps the four passes when a bucket exceeds the
-    capacity -- 18432 up to 18.3 M elements (the half-size bucket kernel, two workgroups per CU), 36864 beyond.  Uniform
+    capacity -- 18432 up to 18.1 M elements (the half-size bucket kernel, two workgroups per CU), 36864 beyond.  Uniform
     keys with ONE bucket brought to exactly the capacity (the plan applies: word 1 of the storage says 3) and to one more
     (it does not), keys-only or key+value (values = iota: the permutation itself), direct and indirect with a smaller
     device-side count; the first sizes of the plan, one round of tiles, both sides of the switch between the two bucket

@@ -227,7 +227,7 @@ uint32_t MsdBits(bool atomicRank, bool keyValue, uint32_t elementCount, uint32_t
   static const int forcedBits = TuningKnob("VRDX_MSD_BITS");  // measurements: 10 | 11 wherever the capacity allows
   static const int knobLast = TuningKnob("VRDX_HYBRID_HEADROOM_LAST");
   if (!enabled || !atomicRank) return 0;
-  // From where the EIGHT-bit plan ends (8.1 M: hybridCap == 0), keys-only and key+value.  Up to 18.3 M elements the buckets
+  // From where the EIGHT-bit plan ends (8.1 M: hybridCap == 0), keys-only and key+value.  Up to 18.1 M elements the buckets
   // hold at most 18432 and the half-size bucket kernel sorts them, two workgroups to a CU: with it the plan is 8-15 % faster
   // than round 4's nine-bit hybrid plan and the four passes at one round of tiles, which key+value sorts of these sizes
   // took before (profiles/r05_msd_half_buckets.txt); that plan's kernels are gone since.
@@ -241,7 +241,9 @@ uint32_t MsdBits(bool atomicRank, bool keyValue, uint32_t elementCount, uint32_t
     if (mean * (uint64_t)(knobLast > 0 ? knobLast : 103) / 100u <= cap) {
       // buckets of half the size: the bucket kernel of 512 threads, two workgroups per CU (bucket_sort2_half_kernel)
       static const int half = TuningKnob("VRDX_MSD_HALF");
-      if (bits == 10 && half != 0 && mean * (uint64_t)(knobLast > 0 ? knobLast : 103) / 100u <= vrdx::kMsdHalfCap)
+      // (4 % of headroom here: 5.3 sigma of a uniform bucket of 17700; the 3 % of the full size would be 4 sigma at this
+      // capacity, and with 1024 buckets one sort in thirty at the top of the range would be turned down)
+      if (bits == 10 && half != 0 && mean * (uint64_t)(knobLast > 0 ? knobLast : 104) / 100u <= vrdx::kMsdHalfCap)
         *capacity = vrdx::kMsdHalfCap;
       return bits;
     }

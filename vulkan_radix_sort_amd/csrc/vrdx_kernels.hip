@@ -1793,7 +1793,7 @@ __global__ __launch_bounds__(THREADS) void bucket_sort_kernel(BucketSortArgs a) 
 //                          independent, which is what a row of 2048 status words per tile would have made expensive;
 //   bucket_sort2_kernel    every bucket (<= 36864 elements) by its remaining 21-22 bits: two stable passes of <= 11 bits
 //                          through the LDS staging buffer; bucket_sort2_half_kernel: the same in 512 threads for buckets
-//                          of <= 18432 elements (sorts of up to 18.3 M), two workgroups to a CU.
+//                          of <= 18432 elements (sorts of up to 18.1 M), two workgroups to a CU.
 //
 // A stable scatter by the top bits followed by a stable sort of each bucket by the bits below is the permutation of
 // four stable LSD passes.  If any bucket exceeds the capacity (skewed or few-distinct keys, keys below 2^21) the last two
@@ -2529,7 +2529,7 @@ template <uint32_t BITS, int KPT, bool KV>
 __global__ __launch_bounds__(1024) void bucket_sort2_kernel(MsdArgs a) {
   BucketSort2Body<BITS, KPT, KV>(a);
 }
-// Buckets of no more than 18432 elements (sorts of up to 18.3 M elements by ten bits): workgroups of 512 threads and
+// Buckets of no more than 18432 elements (sorts of up to 18.1 M elements by ten bits): workgroups of 512 threads and
 // 72 KiB of LDS, TWO to a CU -- one loads or scans while the other ranks.  A bucket has a fixed cost of 5.7 us in the
 // kernel above (load latency, two column scans, eight barriers), half the time of a bucket of 8192 keys, and with one
 // workgroup per CU nothing runs beside it.
