@@ -22,7 +22,10 @@
  *   VkQueryPool                 : VrdxHipQueryPool (array of hipEvent_t), see vrdxHipCreateQueryPool.
  *
  * All arithmetic on this path is 32-bit unsigned integer; keys are sorted ascending, the sort is
- * stable, and results land back in keysBuffer / valuesBuffer (4 ping-pong passes).
+ * stable, and results land back in keysBuffer / valuesBuffer.  How many trips through memory a sort
+ * makes is the library's business and depends on its size (vrdxHipDescribePlan): one workgroup up to
+ * 16384 elements; one scatter + one in-LDS sort per bucket (two trips) up to 67.1 M elements when the
+ * device finds that every bucket fits; four ping-pong passes like the reference's otherwise.
  */
 #ifndef VK_RADIX_SORT_H
 #define VK_RADIX_SORT_H
@@ -127,12 +130,24 @@ void vrdxGetSorterKeyValueStorageRequirements(VrdxSorter sorter, uint32_t maxEle
  * N=15 (same slot contract as the reference):
  * query + 0: start
  * query + 1: after the state clear ("transfer")
- * query + 2 + (3 * i) + 0: upsweep of pass i   (ours: the fused 4-digit histogram for i = 0;
- *                                               coincides with the previous slot for i > 0)
- * query + 2 + (3 * i) + 1: spine of pass i     (ours: always coincides with the slot before --
- *                                               the scan is a decoupled look-back inside downsweep)
- * query + 2 + (3 * i) + 2: downsweep of pass i (ours: the onesweep rank+scatter kernel)
+ * query + 2 + (3 * i) + 0: upsweep of pass i
+ * query + 2 + (3 * i) + 1: spine of pass i
+ * query + 2 + (3 * i) + 2: downsweep of pass i
  * query + 14: sort end
+ *
+ * What lies between two slots here, by the plan vrdxHipDescribePlan reports (slots that have no stage of
+ * their own coincide with the slot before them, so every difference is >= 0 and ts[14] - ts[0] is the sort):
+ *   FOUR_PASSES   [1,2] the fused 4-digit histogram; [3 i + 3, 3 i + 4] pass i (rank + look-back + scatter in
+ *                 one kernel: the "spine" slot 3 i + 3 coincides with the "upsweep" slot 3 i + 2, and that one
+ *                 with the previous pass's "downsweep" slot for i > 0)
+ *   HYBRID8       the same, plus [4,5] = one workgroup per bucket (pass 1's "upsweep"); passes 1-3 return at once
+ *                 when the device takes the plan
+ *   MSD           [0,1] prologue (clear + window choice); [1,2] histogram; [2,3] spine; [3,4] scatter by the
+ *                 window bits; [4,5] one workgroup per bucket; the passes that are launches of their own follow
+ *                 in their "downsweep" slots ([6,7] pass 1, [9,10] pass 2, [12,13] pass 3) and return at once
+ *                 when the device takes the plan (keys-only: passes 0 and 1 are second roles of the scatter and
+ *                 bucket launches and have no slot)
+ *   ONE_WORKGROUP [13,14] the one kernel
  */
 void vrdxCmdSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t elementCount,
                  VkBuffer keysBuffer, VkDeviceSize keysOffset, VkBuffer storageBuffer,
@@ -226,7 +241,7 @@ uint64_t vrdxHipEventOverheadNs(VkCommandBuffer commandBuffer);
 #define VRDX_HIP_PLAN_FOUR_PASSES 2u   /* fused histogram + four onesweep passes: 36 B/key, 68 B/pair */
 #define VRDX_HIP_PLAN_HYBRID8 3u       /* histogram + one scatter by the highest varying byte + one in-LDS sort per bucket */
 #define VRDX_HIP_PLAN_HYBRID9 4u       /* round 4's nine-bit hybrid plan: no longer built (the MSD plan took its sizes); never reported, the value stays reserved */
-#define VRDX_HIP_PLAN_MSD 5u           /* histogram + scatter by the top 10 / 11 bits + two in-LDS passes per bucket */
+#define VRDX_HIP_PLAN_MSD 5u           /* histogram + scatter by a 10 / 11-bit window (chosen on the device below the keys' common prefix) + up to two in-LDS passes per bucket */
 typedef struct VrdxHipPlanInfo {
   uint32_t plan;                    /* VRDX_HIP_PLAN_* */
   uint32_t bits;                    /* digits of the plan's scatter through memory (8, 9, 10, 11; 0 otherwise) */
@@ -235,6 +250,24 @@ typedef struct VrdxHipPlanInfo {
   uint32_t launches;                /* kernel launches recorded (fills and copies not counted) */
 } VrdxHipPlanInfo;
 void vrdxHipDescribePlan(VrdxSorter sorter, uint32_t elementCount, int keyValue, VrdxHipPlanInfo* info);
+
+/* What the DEVICE made of the plan of the last sort that used this storage (word 1 of the storage; synchronises the
+ * stream): vrdxHipDescribePlan is the host's intention, this is the verdict.  Meaningful for the two plans that are
+ * decided on the device; a sort that ran the four passes leaves one of the "turned down" values. */
+#define VRDX_HIP_VERDICT_NONE 0u            /* no plan was taken: the four passes ran (also: FOUR_PASSES / ONE_WORKGROUP sorts) */
+#define VRDX_HIP_VERDICT_HYBRID8_RUNS 1u    /* HYBRID8: launch 0 scattered by the highest varying byte, the buckets were sorted in LDS */
+#define VRDX_HIP_VERDICT_HYBRID8_DECLINED 2u /* HYBRID8: a bucket did not fit, the four passes ran */
+#define VRDX_HIP_VERDICT_MSD_RUNS 3u        /* MSD: scatter + bucket launches sorted the input (bytesPerElement applies) */
+#define VRDX_HIP_VERDICT_MSD_SORTED 4u      /* MSD: all keys identical -- nothing was moved */
+uint32_t vrdxHipReadPlanVerdict(VkCommandBuffer commandBuffer, VkBuffer storageBuffer, VkDeviceSize storageOffset);
+
+/* How many sorts this sorter recorded with the MSD plan in front (*pRecorded, counted on the host when the sort is
+ * recorded) and how many of those the device turned down (*pDeclined, counted on the device when the sort runs: a bucket
+ * beyond the capacity, a key outside the sampled prefix, a sample that rules the plan out) -- such sorts run the four
+ * passes and cost 1.3-1.5x the plan.  Uniform keys at the very top of a plan's size range are turned down with small
+ * probability by design (3-4 % of headroom); a caller that sees the ratio rise knows its keys are skewed.  Synchronises
+ * the stream; either pointer may be NULL. */
+VkResult vrdxHipReadPlanCounters(VrdxSorter sorter, VkCommandBuffer commandBuffer, uint32_t* pRecorded, uint32_t* pDeclined);
 
 /* Library build info: "vrdx-hip <version> gfx950 tiles at 2^25: keys=<threads>x<keys per thread>[x<sub-tiles>]
  * key-value=... (size-adaptive | forced)". */

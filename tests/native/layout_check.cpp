@@ -63,10 +63,12 @@ int main() {
             const vrdx::StorageLayout lm = vrdx::MakeLayout(n, VRDX_STORAGE_ALIGN, plan.tiles, 0x7f0000001000ull + address,
                                                             plan.blockSums, bits, msdTiles);
             ++cases;
-            ok = ok && vrdx::LayoutFits(lm, n) && lm.clearBytes == 16 + 4096;
-            ok = ok && (address + lm.msdCountsOffset) % 128 == 0 && lm.msdCountsBytes == msdTiles * ((uint64_t)2 << bits);
-            ok = ok && lm.msdBucketOffset == lm.msdCountsOffset + lm.msdCountsBytes;
-            ok = ok && lm.statusOffset == lm.msdBucketOffset + ((uint64_t)8 << bits) && (address + lm.statusOffset) % 128 == 0;
+            // bucket sizes (inside the prefix the fill zeroes) and bucket bases on the first line behind the table, the per-tile
+            // counts behind them, status region 0 behind those
+            ok = ok && vrdx::LayoutFits(lm, n) && (address + lm.msdBucketOffset) % 128 == 0 && lm.msdBucketOffset >= 16 + 4096 &&
+                 lm.msdBucketOffset < 16 + 4096 + 128 && lm.clearBytes == lm.msdBucketOffset + ((uint64_t)4 << bits);
+            ok = ok && lm.msdCountsOffset == lm.msdBucketOffset + ((uint64_t)8 << bits) && lm.msdCountsBytes == msdTiles * ((uint64_t)2 << bits);
+            ok = ok && lm.statusOffset == lm.msdCountsOffset + lm.msdCountsBytes && (address + lm.statusOffset) % 128 == 0;
             ok = ok && lm.statusClearOffset == lm.statusOffset && lm.statusClearBytes == lm.regionBytes;
             ok = ok && (address + lm.inoutOffset) % 128 == 0 && lm.valuesOffset >= lm.inoutOffset + (uint64_t)n * 4;
           }

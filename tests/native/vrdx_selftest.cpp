@@ -368,35 +368,82 @@ int Parity(Harness& h, bool quick) {
 // argv sizes override the list.
 int MsdParity(Harness& h, const std::vector<uint32_t>& wanted) {
   int failures = 0, cases = 0;
-  auto run = [&](Mode m, const std::vector<uint32_t>& k, const std::vector<uint32_t>& v, uint32_t maxCount, const char* label) {
+  // expect: the verdict the device must reach (VRDX_HIP_VERDICT_MSD_RUNS / _MSD_SORTED), 0 = "the four passes ran", -1 = either
+  auto run = [&](Mode m, const std::vector<uint32_t>& k, const std::vector<uint32_t>& v, uint32_t maxCount, const char* label,
+                 int expect = -1) {
     ++cases;
-    if (!RunCase(h, m, k, v, maxCount, label, true)) ++failures;
+    bool ok = RunCase(h, m, k, v, maxCount, label, true);
+    const uint32_t verdict = vrdxHipReadPlanVerdict((VkCommandBuffer)h.stream, (VkBuffer)h.dStorage, 0);
+    const bool taken = verdict == VRDX_HIP_VERDICT_MSD_RUNS || verdict == VRDX_HIP_VERDICT_MSD_SORTED;
+    // (the expectation holds where the MSD plan is recorded: the first size of the list is the eight-bit plan's last)
+    VrdxHipPlanInfo info;
+    vrdxHipDescribePlan(h.sorter, maxCount, m == Mode::KeyValue || m == Mode::KeyValueIndirect, &info);
+    if (info.plan == VRDX_HIP_PLAN_MSD && expect >= 0 && (expect == 0 ? taken : verdict != (uint32_t)expect)) {
+      std::printf("FAIL %-34s %-12s n=%zu verdict %u, expected %d\n", label, ModeName(m), k.size(), verdict, expect);
+      ok = false;
+    }
+    if (!ok) ++failures;
     std::fflush(stdout);
   };
   std::vector<uint32_t> sizes = wanted;
-  if (sizes.empty()) sizes = {8144129u, 18149376u, 18149377u, 20000003u, 1u << 25, 36000001u, 45000000u};
+  if (sizes.empty()) sizes = {8144200u, 18149376u, 18149377u, 20000003u, 1u << 25, 36000001u, 45000000u};
+  const int RUNS = VRDX_HIP_VERDICT_MSD_RUNS, SORTED = VRDX_HIP_VERDICT_MSD_SORTED;
   for (uint32_t n : sizes) {
     std::vector<uint32_t> v;
     auto k = Mt(n, 1, 32, &v);
-    run(Mode::Keys, k, v, n, "msd uniform");
-    run(Mode::KeyValue, k, v, n, "msd uniform");
+    run(Mode::Keys, k, v, n, "msd uniform", RUNS);
+    run(Mode::KeyValue, k, v, n, "msd uniform", RUNS);
     run(Mode::KeyValueIndirect, k, v, n + n / 7 + 5000, "msd uniform, larger bound");
     run(Mode::KeysIndirect, k, v, n + 70000, "msd uniform, larger bound");
     std::vector<uint32_t> iota(n);
     for (uint32_t i = 0; i < n; ++i) iota[i] = i;
-    // 24-bit keys: every key in the top buckets 0..7 -- overflow, the four passes (one of them trivial) run
+    // 24-bit keys (round 6): the window the prologue chooses lies below their eight constant bits
     auto k24 = Mt(n, 3, 24, nullptr);
-    run(Mode::KeyValue, k24, iota, n, "msd declines: 24-bit keys");
+    run(Mode::KeyValue, k24, iota, n, "msd window: 24-bit keys", RUNS);
+    run(Mode::Keys, k24, iota, n, "msd window: 24-bit keys", RUNS);
+    // ... with ONE key outside that prefix, at the very end (no sample sees it: the count must): the four passes
+    k24[n - 1] = 0x81234567u;
+    run(Mode::KeyValue, k24, iota, n, "msd declines: prefix broken at n-1", 0);
+    k24[n - 1] &= 0xFFFFFFu;
+    k24[n / 3] |= 0x01000000u;
+    run(Mode::Keys, k24, iota, n, "msd declines: prefix broken inside", 0);
+    // 12-bit keys: ten bits of window, two bits for the local passes; 8-bit keys: at most 256 buckets can hold anything, which
+    // at these sizes is more than they take -> turned down by the prologue
+    auto k12 = Mt(n, 5, 12, nullptr);
+    run(Mode::KeyValue, k12, iota, n, "msd window: 12-bit keys", n <= 37000000u ? RUNS : -1);  // (beyond: 1024 buckets cannot hold them)
+    auto k8 = Mt(n, 6, 8, nullptr);
+    run(Mode::KeyValue, k8, iota, n, "msd declines: 8-bit keys", 0);
     // duplicates inside buckets that fit: stability of the scatter and of both bucket passes (keys = 11 top bits | 3 low bits)
     std::mt19937 g(11);
     std::vector<uint32_t> dup(n);
     for (auto& x : dup) { const uint32_t r = g(); x = (r & 0xFFE00000u) | (r & 7u) | ((r >> 3 & 1u) << 12); }
-    run(Mode::KeyValue, dup, iota, n, "msd duplicates values=iota");
+    run(Mode::KeyValue, dup, iota, n, "msd duplicates values=iota", RUNS);
+    // the same duplicates below a 9-bit prefix: window bits 12 ... 22 | one bit | three low bits, ONE local pass or two
+    for (auto& x : dup) x = 0x5A800000u | (x >> 9);
+    run(Mode::KeyValue, dup, iota, n, "msd window: duplicates under a prefix", RUNS);
     // one heavy bucket among uniform ones: a tenth of the keys share their top 11 bits
     for (uint32_t i = 0; i < n; ++i) dup[i] = (g() % 10u == 0) ? (0x5A400000u | (g() & 0x1FFFFFu)) : g();
-    run(Mode::KeyValue, dup, iota, n, "msd declines: one heavy bucket");
+    run(Mode::KeyValue, dup, iota, n, "msd declines: one heavy bucket", 0);
+    // dense ids: descending, ascending (whether they fit depends on how much of the power of two above n they fill;
+    // the verdict is checked where it is certain: n = 2^25)
     for (uint32_t i = 0; i < n; ++i) dup[i] = n - 1 - i;
-    run(Mode::Keys, dup, iota, n, "msd declines: descending");
+    run(Mode::Keys, dup, iota, n, "msd window: descending", n == (1u << 25) ? RUNS : -1);
+    run(Mode::KeyValue, dup, iota, n, "msd window: descending", n == (1u << 25) ? RUNS : -1);
+    for (uint32_t i = 0; i < n; ++i) dup[i] = i;
+    run(Mode::KeyValue, dup, iota, n, "msd window: ascending", n == (1u << 25) ? RUNS : -1);
+    // keys that differ in their low ten bits only: the window does not go below bit 2, 256 buckets can hold something
+    for (uint32_t i = 0; i < n; ++i) dup[i] = 0xABCDE000u | (g() & 0x3FFu);
+    run(Mode::KeyValue, dup, iota, n, "msd: ten-bit keys");
+    // all keys identical: nothing to do, and the plan says so
+    std::fill(dup.begin(), dup.end(), 0x12345678u);
+    run(Mode::KeyValue, dup, iota, n, "msd: all equal", SORTED);
+    run(Mode::Keys, dup, iota, n, "msd: all equal", SORTED);
+    dup[n - 2] = 0x12345679u;  // ... but one
+    run(Mode::KeyValue, dup, iota, n, "msd declines: all equal but one", 0);
+    // four distinct values
+    const uint32_t four[4] = {3u, 0xFFFFFFFFu, 0x00010000u, 0x7F000000u};
+    for (uint32_t i = 0; i < n; ++i) dup[i] = four[g() & 3];
+    run(Mode::KeyValue, dup, iota, n, "msd declines: four values", 0);
   }
   std::printf("msd parity: %d cases, %d failures\n", cases, failures);
   return failures;
@@ -666,13 +713,17 @@ int Adversarial(Harness& h, int lg) {
   // the last two: every tile holds each digit of pass 0 exactly 128 times, so every run a tile writes in
   // pass 0 is 512 bytes -- starting on a 512-byte boundary ("balanced"), or 13 keys behind one
   // ("balanced+13": every run then begins and ends inside a 128-byte line).  Only pass 0 is comparable.
+  // round 6: "24-bit" = DataGenerator::Generate(n, 24)-style keys (/root/reference/bench/data_generator.cc:15), "outlier" =
+  // ascending keys with one key at the end that breaks their common prefix (the MSD plan's window is a guess from a sample:
+  // the count must turn it down), "gaussian" = a sum of four uniform bytes in the top byte (mild skew: 1.5x the mean bucket)
   const char* names[] = {"uniform", "all-equal", "all-0xFFFFFFFF", "descending", "ascending", "few-distinct(4)",
-                         "balanced", "balanced+13"};
+                         "24-bit", "outlier", "gaussian", "balanced", "balanced+13"};
+  constexpr int kPatterns = 11;
   double base[2] = {0, 0};
   int failures = 0;
-  std::printf("%-18s %-5s %10s %12s %10s %s\n", "keys", "sort", "gpu_ms", "GItems/s", "slowdown", "parity");
+  std::printf("%-18s %-5s %10s %12s %10s %-8s %s\n", "keys", "sort", "gpu_ms", "GItems/s", "slowdown", "parity", "verdict");
   const char* const patternsEnv = std::getenv("VRDX_SELFTEST_PATTERNS");  // the first k input patterns only
-  const int patterns = patternsEnv != nullptr ? std::min(8, std::max(1, std::atoi(patternsEnv))) : 8;
+  const int patterns = patternsEnv != nullptr ? std::min(kPatterns, std::max(1, std::atoi(patternsEnv))) : kPatterns;
   for (int pattern = 0; pattern < patterns; ++pattern) {
     const uint32_t four[4] = {3u, 0xFFFFFFFFu, 0x00010000u, 0x7F000000u};
     for (uint32_t i = 0; i < n; ++i) {
@@ -683,7 +734,14 @@ int Adversarial(Harness& h, int lg) {
         case 3: k[i] = n - 1 - i; break;
         case 4: k[i] = i; break;
         case 5: k[i] = four[g() & 3]; break;
-        case 6: k[i] = (i & 0xFFu) * 0x01010101u; break;
+        case 6: k[i] = g() >> 8; break;
+        case 7: k[i] = i + 1 < n ? i : 0x80000000u; break;
+        case 8: {
+          const uint32_t r = g(), r2 = g();
+          k[i] = ((((r & 255u) + ((r >> 8) & 255u) + ((r >> 16) & 255u) + (r >> 24)) >> 2) << 24) | (r2 & 0x00FFFFFFu);
+          break;
+        }
+        case 9: k[i] = (i & 0xFFu) * 0x01010101u; break;
         default: k[i] = i < 13 ? 0u : ((i - 13) & 0xFFu) * 0x01010101u; break;
       }
     }
@@ -692,6 +750,7 @@ int Adversarial(Harness& h, int lg) {
     for (int kv = 0; kv < 2; ++kv) {
       std::vector<uint64_t> times;
       bool ok = true;
+      uint32_t verdict = 0;
       double stageHist = 0, stagePass[4] = {0, 0, 0, 0};
       for (int run = 0; run < 6; ++run) {
         HIP_OK(hipMemcpy(h.dKeys, k.data(), (size_t)n * 4, hipMemcpyHostToDevice));
@@ -716,14 +775,16 @@ int Adversarial(Harness& h, int lg) {
           HIP_OK(hipMemcpy(gv.data(), h.dKeys + inout, (size_t)n * 4, hipMemcpyDeviceToHost));
           ok = gk == ek && (!kv || gv == ev);
           if (vrdxHipReadStatus((VkCommandBuffer)h.stream, (VkBuffer)h.dStorage, StorageOffset()) != 0) ok = false;
+          verdict = vrdxHipReadPlanVerdict((VkCommandBuffer)h.stream, (VkBuffer)h.dStorage, StorageOffset());
         }
       }
       const double ms = Median(times) / 1e6;
       if (pattern == 0) base[kv] = ms;
       if (!ok) ++failures;
-      std::printf("%-18s %-5s %10.4f %12.3f %9.2fx %-8s hist %.4f | passes %.4f %.4f %.4f %.4f\n", names[pattern],
-                  kv ? "kv" : "keys", ms, n / (ms * 1e-3) / 1e9, ms / base[kv], ok ? "ok" : "MISMATCH", stageHist,
-                  stagePass[0], stagePass[1], stagePass[2], stagePass[3]);
+      std::printf("%-18s %-5s %10.4f %12.3f %9.2fx %-8s %-8s hist %.4f | passes %.4f %.4f %.4f %.4f\n", names[pattern],
+                  kv ? "kv" : "keys", ms, n / (ms * 1e-3) / 1e9, ms / base[kv], ok ? "ok" : "MISMATCH",
+                  verdict == VRDX_HIP_VERDICT_MSD_RUNS ? "msd" : verdict == VRDX_HIP_VERDICT_MSD_SORTED ? "sorted" : "passes",
+                  stageHist, stagePass[0], stagePass[1], stagePass[2], stagePass[3]);
       std::fflush(stdout);
     }
   }

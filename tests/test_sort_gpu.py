@@ -111,8 +111,9 @@ def decline_msd(keys):
 
 
 def plan_word(storage):
-    """word 1 of the storage: 3 = the MSD plan recorded in front of the passes took the sort"""
-    return int(storage[4:8].cpu().numpy().view(np.uint32)[0])
+    """low byte of word 1 of the storage (what vrdxHipReadPlanVerdict returns): 3 = the MSD plan recorded in front of the
+    passes took the sort, 4 = it found all keys identical and left them alone"""
+    return int(storage[4:8].cpu().numpy().view(np.uint32)[0]) & 0xFF
 
 
 SIZES = [0, 1, 2, 63, 64, 65, 511, 512, 513, 4095, 4096, 4097, 8191, 8192, 8193, 12411, 16383, 16384,
@@ -635,28 +636,68 @@ def test_msd_plan_and_its_fallback_at_the_bucket_capacity(torch_mod, sorter, ora
 
 
 @pytest.mark.parametrize("n", [MSD_FROM + 7, (1 << 25) - 12345])
-def test_msd_plan_stability_and_inputs_it_declines(torch_mod, sorter, oracle, n):
+def test_msd_plan_stability_window_choice_and_inputs_it_declines(torch_mod, sorter, oracle, n):
     """The MSD plan on duplicate-heavy keys that fit its buckets (keys = eleven top bits | one middle bit | three low bits:
-    the stability of the scatter and of both bucket passes is what keeps equal keys' values in input order) and the
-    inputs it must turn down on the device: 24-bit keys, descending and ascending keys, four distinct values, all-equal."""
+    the stability of the scatter and of both bucket passes is what keeps equal keys' values in input order); on inputs
+    whose top bits are constant, which since round 6 it TAKES -- the device puts the scatter's window below the common
+    prefix of a sample of the keys (24-bit keys like DataGenerator::Generate(n, 24), /root/reference/bench/data_generator.cc:15;
+    the same duplicates under a nine-bit prefix; twelve-bit keys: one short local pass); and on the inputs it must turn
+    down: the sample is only the guess, so ONE key outside the prefix, planted where no sample looks (index n - 1 is
+    sampled: n - 2 and the middle are not), must send the sort to the four passes and still come out bit-exact; four distinct
+    values; eight-bit keys.  All keys identical: verdict 4, nothing moved."""
+    import vulkan_radix_sort_amd as vrdx
     rng = np.random.default_rng(n)
     iota = np.arange(n, dtype=np.uint32)
     r = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
     dup = (r & np.uint32(0xFFE00000)) | (r & np.uint32(7)) | (((r >> np.uint32(3)) & np.uint32(1)) << np.uint32(12))
-    kept = []
-    gk, gp = gpu_sort(torch_mod, sorter, dup, iota, storage_out=kept)
-    ek, ep, _ = oracle.sort(dup, iota)
-    assert np.array_equal(gk, ek) and np.array_equal(gp, ep) and plan_word(kept[0]) == 3
-    four = np.array([0xFFFFFFFF, 0, 0x80000001, 0x7FFFFF00], np.uint32)[rng.integers(0, 4, n)]
-    for name, k in (("24-bit", r >> np.uint32(8)), ("descending", (n - 1 - iota).astype(np.uint32)), ("ascending", iota.copy()),
-                    ("four values", four), ("all equal", np.full(n, 0x12345678, np.uint32))):
+    stream = torch_mod.cuda.current_stream().cuda_stream
+
+    def run(name, k, expect):
         kept = []
         gk, gp = gpu_sort(torch_mod, sorter, k, iota, storage_out=kept)
         ek, ep, _ = oracle.sort(k, iota)
         assert np.array_equal(gk, ek) and np.array_equal(gp, ep), name
-        assert plan_word(kept[0]) != 3, name
-        gk, _ = gpu_sort(torch_mod, sorter, k)
-        assert np.array_equal(gk, ek), name
+        verdict = sorter.read_plan_verdict(stream, kept[0].data_ptr(), 0)
+        assert verdict == plan_word(kept[0]) and verdict == expect, (name, verdict, expect)
+        kept = []
+        gk, _ = gpu_sort(torch_mod, sorter, k, storage_out=kept)
+        assert np.array_equal(gk, ek) and plan_word(kept[0]) == expect, name
+
+    runs, sorted_, passes = vrdx.VERDICT_MSD_RUNS, vrdx.VERDICT_MSD_SORTED, vrdx.VERDICT_NONE
+    run("duplicates", dup, runs)
+    k24 = r >> np.uint32(8)
+    run("24-bit", k24, runs)
+    run("duplicates under a prefix", np.uint32(0x5A800000) | (dup >> np.uint32(9)), runs)
+    run("12-bit", r >> np.uint32(20), runs)
+    for where in (n - 2, n // 2 + 1):
+        broken = k24.copy()
+        broken[where] |= np.uint32(0x40000000)
+        run(f"24-bit with one key outside the prefix at {where}", broken, passes)
+    four = np.array([0xFFFFFFFF, 0, 0x80000001, 0x7FFFFF00], np.uint32)[rng.integers(0, 4, n)]
+    run("four values", four, passes)
+    run("8-bit", r >> np.uint32(24), passes)
+    same = np.full(n, 0x12345678, np.uint32)
+    run("all equal", same, sorted_)
+    same[n - 2] = 0x12345679
+    run("all equal but one", same, passes)
+    recorded, declined = sorter.read_plan_counters(stream)
+    assert recorded >= 22 and declined >= 10 and declined < recorded, (recorded, declined)
+
+
+@pytest.mark.parametrize("n", [1 << 25, 20_000_003, 12_000_001])
+def test_msd_plan_takes_dense_sorted_ids(torch_mod, sorter, oracle, n):
+    """BASELINE config 4's descending keys (and ascending ones): N - 1 - i fills the power of two above N well enough at
+    these sizes that every bucket of the window the device chooses fits, so the two-trip plan runs (round 5: the four
+    passes + 10 %).  Stable (values = iota), keys-only as well."""
+    iota = np.arange(n, dtype=np.uint32)
+    for name, k in (("descending", (n - 1 - iota).astype(np.uint32)), ("ascending", iota.copy())):
+        kept = []
+        gk, gp = gpu_sort(torch_mod, sorter, k, iota, storage_out=kept)
+        assert np.array_equal(gk, iota) and np.array_equal(gp, iota if name == "ascending" else (n - 1 - iota)), name
+        assert plan_word(kept[0]) == 3, (name, plan_word(kept[0]))
+        kept = []
+        gk, _ = gpu_sort(torch_mod, sorter, k, storage_out=kept)
+        assert np.array_equal(gk, iota) and plan_word(kept[0]) == 3, name
 
 
 @pytest.mark.parametrize("n", [ROUND, ROUND + 4097, ROUND + ROUND // 4 + 3, 2 * ROUND - 5, 2 * ROUND])
@@ -1080,6 +1121,14 @@ def test_histogram_table_matches_oracle_digit_counts(torch_mod, sorter, oracle, 
     few = np.array([3, 0xFFFFFFFF, 0x00010000, 0x7F000000], np.uint32)[np.random.default_rng(n).integers(0, 4, n)]
     table, _ = _histogram_table_after_sort(torch_mod, sorter, few)
     assert np.array_equal(table, oracle.digit_counts(few))
+    # keys under a common prefix (the MSD plan's histogram kernel then counts byte 3 in a table of its own), also with
+    # a key that breaks the prefix and sends the sort to the four passes, which need all four tables
+    narrow = (k >> np.uint32(7)) | np.uint32(0x04000000)
+    table, _ = _histogram_table_after_sort(torch_mod, sorter, narrow)
+    assert np.array_equal(table, oracle.digit_counts(narrow))
+    narrow[n // 2 + 1] = 0xF0000001
+    table, gk = _histogram_table_after_sort(torch_mod, sorter, narrow)
+    assert np.array_equal(table, oracle.digit_counts(narrow)) and np.array_equal(gk, np.sort(narrow))
     count = n - n // 3
     table, gk = _histogram_table_after_sort(torch_mod, sorter, k, count=count, indirect=True)
     assert np.array_equal(table, oracle.digit_counts(k, count))

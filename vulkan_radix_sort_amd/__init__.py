@@ -25,6 +25,11 @@ from .api import (  # noqa: F401
     STATUS_RANK_ORDER,
     STATUS_COUNT_CLAMPED,
     STATUS_ENQUEUE_REFUSED,
+    VERDICT_NONE,
+    VERDICT_HYBRID8_RUNS,
+    VERDICT_HYBRID8_DECLINED,
+    VERDICT_MSD_RUNS,
+    VERDICT_MSD_SORTED,
 )
 
 __all__ = [
@@ -44,4 +49,9 @@ __all__ = [
     "STATUS_RANK_ORDER",
     "STATUS_COUNT_CLAMPED",
     "STATUS_ENQUEUE_REFUSED",
+    "VERDICT_NONE",
+    "VERDICT_HYBRID8_RUNS",
+    "VERDICT_HYBRID8_DECLINED",
+    "VERDICT_MSD_RUNS",
+    "VERDICT_MSD_SORTED",
 ]

@@ -53,6 +53,8 @@ EXPORTED_SYMBOLS = (
     "vrdxHipRecheck",
     "vrdxHipEventOverheadNs",
     "vrdxHipDescribePlan",
+    "vrdxHipReadPlanVerdict",
+    "vrdxHipReadPlanCounters",
     "vrdxHipVersionString",
 )
 
@@ -64,6 +66,13 @@ STATUS_ENQUEUE_REFUSED = 0x80000000
 
 # VRDX_HIP_PLAN_* (include/vk_radix_sort.h)
 PLAN_NAMES = {0: "none", 1: "one-workgroup", 2: "four-passes", 3: "hybrid-8", 4: "hybrid-9", 5: "msd"}
+
+# VRDX_HIP_VERDICT_* (include/vk_radix_sort.h): what the DEVICE made of the plan of the last sort on a storage
+VERDICT_NONE = 0
+VERDICT_HYBRID8_RUNS = 1
+VERDICT_HYBRID8_DECLINED = 2
+VERDICT_MSD_RUNS = 3
+VERDICT_MSD_SORTED = 4
 
 
 class VrdxError(RuntimeError):
@@ -172,6 +181,10 @@ def load_library() -> ctypes.CDLL:
     lib.vrdxHipEventOverheadNs.argtypes = [vp]
     lib.vrdxHipDescribePlan.restype = None
     lib.vrdxHipDescribePlan.argtypes = [vp, u32, ctypes.c_int, ctypes.POINTER(VrdxHipPlanInfo)]
+    lib.vrdxHipReadPlanVerdict.restype = u32
+    lib.vrdxHipReadPlanVerdict.argtypes = [vp, vp, u64]
+    lib.vrdxHipReadPlanCounters.restype = ctypes.c_int32
+    lib.vrdxHipReadPlanCounters.argtypes = [vp, vp, ctypes.POINTER(u32), ctypes.POINTER(u32)]
     lib.vrdxHipVersionString.restype = ctypes.c_char_p
     lib.vrdxHipVersionString.argtypes = []
     _LIB = lib
@@ -317,6 +330,26 @@ class Sorter:
         info = VrdxHipPlanInfo()
         self._lib.vrdxHipDescribePlan(self.handle, element_count, 1 if key_value else 0, ctypes.byref(info))
         return info
+
+    def read_plan_verdict(self, command_buffer, storage, storage_offset=0) -> int:
+        """``vrdxHipReadPlanVerdict``: what the device made of the plan of the last sort on this storage (``VERDICT_*``):
+        ``describe_plan`` is the host's intention, this is what ran.  Synchronises the stream."""
+        return int(self._lib.vrdxHipReadPlanVerdict(_handle(command_buffer), _handle(storage), storage_offset))
+
+    def plan_taken(self, command_buffer, storage, storage_offset=0) -> bool:
+        """True when the two-trip plan recorded for the last sort on this storage (hybrid-8 or msd) actually ran."""
+        return self.read_plan_verdict(command_buffer, storage, storage_offset) in (
+            VERDICT_HYBRID8_RUNS, VERDICT_MSD_RUNS, VERDICT_MSD_SORTED)
+
+    def read_plan_counters(self, command_buffer):
+        """``vrdxHipReadPlanCounters``: (sorts recorded with the MSD plan in front, how many of them the device turned
+        down) since the sorter was created.  Synchronises the stream."""
+        recorded, declined = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        r = self._lib.vrdxHipReadPlanCounters(self.handle, _handle(command_buffer), ctypes.byref(recorded),
+                                              ctypes.byref(declined))
+        if r != VK_SUCCESS:
+            raise VrdxError("vrdxHipReadPlanCounters", r)
+        return int(recorded.value), int(declined.value)
 
     def recheck(self) -> None:
         """``vrdxHipRecheck``: repeats the device check behind the one-atomic ranking and falls back to the ballot

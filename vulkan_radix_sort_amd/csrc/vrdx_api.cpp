@@ -37,6 +37,11 @@ struct VrdxSorter_T {
   // vrdxHipReadSorterStatus clears it, so a caller that reuses ONE storage buffer for many sorts (each
   // of which clears the storage's own failure word) still learns about a failure in any of them.
   uint32_t* stickyStatus = nullptr;
+  // Second device word, right behind it: MSD plans the DEVICE turned down (a bucket beyond the capacity, a key outside the
+  // sampled prefix, a sample that ruled the plan out) -- those sorts ran the four passes recorded behind the plan.  Next to
+  // it the number of sorts recorded with the plan in front (host side).  vrdxHipReadPlanCounters.
+  uint32_t* declinedPlans = nullptr;
+  mutable std::atomic<uint32_t> plansRecorded{0};
   // Host side of the same diagnosis: set when an enqueue of a sort (fill, copy or kernel launch) was
   // refused by the runtime -- the entry points return void, so this is the only place it can go.
   // Reported as bit 31 by vrdxHipReadSorterStatus, which clears it.
@@ -322,6 +327,85 @@ vrdx::TilePlan PlanTiles(const VrdxSorter_T* sorter, int configIndex, bool keyVa
                          (uint32_t)c.subTiles, splitForms, evenSplit, tailPercent);
 }
 
+// Everything the host decides about a sort, in ONE place: RecordSort records it and vrdxHipDescribePlan reports it.
+// storageAddress: the absolute address the storage is handed over at -- only its low seven bits matter (the pads in front
+// of the 128-byte aligned regions); 0 is the worst case for what fits, which is what vrdxHipDescribePlan assumes.
+struct SortPlan {
+  bool atomicRank = false;
+  bool oneWorkgroup = false;    // small_sort_kernel: one launch, no storage layout
+  uint32_t hybridCap = 0;       // the eight-bit hybrid plan is recorded with this bucket capacity
+  uint32_t msdBits = 0;         // the MSD plan is recorded in front of the passes (10 | 11)
+  uint32_t msdCap = 0;
+  uint32_t msdTileKeys = 0;
+  uint32_t msdTiles = 0;
+  uint32_t msdFused = 0;        // how many of the plan's launches double as the fallback's first passes (0 | 1 | 2)
+  int configIndex = 0;
+  vrdx::TilePlan tilePlan{};
+  bool blockSums = false;
+  bool fits = true;             // false: not even tiles of full capacity fit the caller's storage (refused)
+  vrdx::StorageLayout layout{};
+  uint32_t launches = 0;        // kernels + fills enqueued
+};
+
+SortPlan PlanSort(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCount, uint64_t storageAddress) {
+  SortPlan p;
+  p.atomicRank = sorter->atomicRank.load(std::memory_order_relaxed);  // one answer for the whole sort
+  const bool adaptive = ForcedConfigIndex() < 0;
+  if (elementCount == 0) return p;
+  if (elementCount <= vrdx::kSmallSortMaxElements && adaptive && SmallSortEnabled()) {
+    p.oneWorkgroup = true;
+    p.launches = 1;
+    p.layout = vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, 0, storageAddress);  // (the failure word)
+    return p;
+  }
+  p.hybridCap = adaptive ? HybridCapacity(p.atomicRank, elementCount) : 0u;
+  p.msdBits = adaptive ? MsdBits(p.atomicRank, keyValue, elementCount, p.hybridCap, &p.msdCap) : 0u;
+  if (p.hybridCap != 0) p.msdBits = 0;  // (VRDX_MSD_FROM below the eight-bit plan's end: that plan keeps its sizes)
+  p.configIndex = ConfigIndex(sorter, keyValue, elementCount, p.atomicRank, p.msdBits != 0);
+  p.tilePlan = PlanTiles(sorter, p.configIndex, keyValue, elementCount, p.atomicRank);
+  // Block sums instead of the look-back chain: sorts of one round (PlanTiles) on the four-pass plan -- with a hybrid
+  // plan recorded, launch 0 may rank by another byte than its pass index, which the block-sum form does not look up.
+  // VRDX_BLOCK_SUMS=0 keeps the classic look-back (measurements).
+  static const int blockSumsKnob = TuningKnob("VRDX_BLOCK_SUMS");
+  p.blockSums = p.tilePlan.blockSums && p.hybridCap == 0 && blockSumsKnob != 0;
+  p.msdTileKeys = MsdTileKeys(elementCount, (uint32_t)sorter->computeUnits);
+  p.msdTiles = vrdx::RoundUp(elementCount, p.msdTileKeys);
+  const uint32_t align = sorter->minStorageBufferOffsetAlignment;
+  p.layout = vrdx::MakeLayout(elementCount, align, p.tilePlan.tiles, storageAddress, p.blockSums, p.msdBits, p.msdTiles);
+  if (p.msdBits != 0 && !vrdx::LayoutFits(p.layout, elementCount)) {
+    // (cannot happen for the sizes MsdBits admits -- tests/native/layout_check.cpp sweeps them -- but the storage is the
+    // caller's: without the plan's rows in front of the status regions the layout fits for every N)
+    p.msdBits = 0;
+    p.layout = vrdx::MakeLayout(elementCount, align, p.tilePlan.tiles, storageAddress, p.blockSums);
+  }
+  if (!vrdx::LayoutFits(p.layout, elementCount)) {
+    // EVERY sort of the general path is checked, not only those with a plan in front: the layout depends on the tile plan, and the
+    // measurement knobs (VRDX_TAIL_SPLIT, VRDX_EVEN_SPLIT, VRDX_TILE_CONFIG) can select plans the offline sweep of
+    // tests/native/layout_check.cpp never saw.  Tiles of the kernel's full capacity without block rows fit for every N
+    // (2 (tiles - 1) KiB <= (P - 1) KiB from 8192 keys per tile up); smaller tiles cannot be helped: the scratch arrays
+    // must not leave the caller's allocation, so that sort is refused and says so (VRDX_HIP_STATUS_ENQUEUE_REFUSED).
+    const vrdx::TileConfig& c = vrdx::kTileConfigs[p.configIndex];
+    p.tilePlan = vrdx::PlanTiles(elementCount, (uint32_t)sorter->computeUnits, (uint32_t)c.threads, (uint32_t)c.keysPerThread,
+                                 (uint32_t)c.subTiles, false, false, 0);
+    p.blockSums = false;
+    p.msdBits = 0;
+    p.layout = vrdx::MakeLayout(elementCount, align, p.tilePlan.tiles, storageAddress, false, 0);
+    p.fits = vrdx::LayoutFits(p.layout, elementCount);
+  }
+  // The MSD plan's scatter launch is ALSO pass 0 of the fallback and its bucket launch pass 1 (one branch on the verdict, on
+  // the device): only passes 2 and 3 remain as launches that return when the plan runs.  The fused kernels exist for the
+  // geometry the recorder selects at these sizes (ConfigIndex: the two-sub-tile kernel), keys-only (the key+value form
+  // measured slower than the launches it saves, vrdx_kernels.hip); with buckets of the half-size kernel (512 threads; the
+  // passes' bodies need 1024) only the scatter launch has a second role.  VRDX_MSD_FUSED=0: none (measurements).
+  static const int fusedKnob = TuningKnob("VRDX_MSD_FUSED");
+  if (p.msdBits != 0 && !keyValue && p.configIndex == kCfg1024x32x2 && fusedKnob != 0)
+    p.msdFused = p.msdCap == vrdx::kMsdCapKeys ? 2u : 1u;
+  // kernels: histogram + four passes (+ the eight-bit plan's bucket launch); the MSD plan: + spine, and those of its scatter
+  // and bucket launches that are not also a pass
+  p.launches = 1u + VRDX_PASSES + (p.msdBits != 0 ? 3u - p.msdFused : 0u) + (p.hybridCap != 0 ? 1u : 0u);
+  return p;
+}
+
 // reference: gpuSort, src/vk_radix_sort.h.in:344-507
 void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t elementCount,
                 VkBuffer indirectBuffer, VkDeviceSize indirectOffset, VkBuffer keysBuffer,
@@ -353,30 +437,15 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     }
   } deviceScope(sorter->device);
 
-  const bool atomicRank = sorter->atomicRank.load(std::memory_order_relaxed);  // one answer for the whole sort
-  uint32_t msdCap = 0;
-  const uint32_t hybridCap = ForcedConfigIndex() < 0 ? HybridCapacity(atomicRank, elementCount) : 0u;
-  uint32_t msdBits = ForcedConfigIndex() < 0 ? MsdBits(atomicRank, keyValue, elementCount, hybridCap, &msdCap) : 0u;
-  if (hybridCap != 0) msdBits = 0;  // (VRDX_MSD_FROM below the eight-bit plan's end: that plan keeps its sizes)
-  const int configIndex = ConfigIndex(sorter, keyValue, elementCount, atomicRank, msdBits != 0);
-  vrdx::TilePlan tilePlan = PlanTiles(sorter, configIndex, keyValue, elementCount, atomicRank);
-  // Block sums instead of the look-back chain: sorts of one round (PlanTiles) on the four-pass plan -- with a hybrid
-  // plan recorded, launch 0 may rank by another byte than its pass index, which the block-sum form does not look up.
-  // VRDX_BLOCK_SUMS=0 keeps the classic look-back (measurements).
-  static const int blockSumsKnob = TuningKnob("VRDX_BLOCK_SUMS");
-  bool blockSums = tilePlan.blockSums && hybridCap == 0 && blockSumsKnob != 0;
   uint8_t* const storage = BufferAddress(storageBuffer, storageOffset);
-  const uint32_t msdTileKeys = MsdTileKeys(elementCount, (uint32_t)sorter->computeUnits);
-  const uint32_t msdTiles = vrdx::RoundUp(elementCount, msdTileKeys);
-  vrdx::StorageLayout layout = vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, tilePlan.tiles,
-                                                (uint64_t)reinterpret_cast<uintptr_t>(storage), blockSums, msdBits, msdTiles);
-  if (msdBits != 0 && !vrdx::LayoutFits(layout, elementCount)) {
-    // (cannot happen for the sizes MsdBits admits -- tests/native/layout_check.cpp sweeps them -- but the storage is the
-    // caller's: without the plan's rows in front of the status regions the layout fits for every N)
-    msdBits = 0;
-    layout = vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, tilePlan.tiles,
-                              (uint64_t)reinterpret_cast<uintptr_t>(storage), blockSums);
-  }
+  const SortPlan plan = PlanSort(sorter, keyValue, elementCount, (uint64_t)reinterpret_cast<uintptr_t>(storage));
+  const bool atomicRank = plan.atomicRank;
+  const uint32_t hybridCap = plan.hybridCap, msdBits = plan.msdBits, msdCap = plan.msdCap;
+  const int configIndex = plan.configIndex;
+  const vrdx::TilePlan& tilePlan = plan.tilePlan;
+  const bool blockSums = plan.blockSums;
+  const uint32_t msdTileKeys = plan.msdTileKeys, msdTiles = plan.msdTiles;
+  const vrdx::StorageLayout& layout = plan.layout;
   uint32_t* const keys = reinterpret_cast<uint32_t*>(BufferAddress(keysBuffer, keysOffset));
   uint32_t* const values =
       keyValue ? reinterpret_cast<uint32_t*>(BufferAddress(valuesBuffer, valuesOffset)) : nullptr;
@@ -397,7 +466,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   // word touched (the
   // general path below costs six launches = 30-45 us however small N is).  Forcing a tile geometry
   // (VRDX_TILE_CONFIG) also forces the general path, which is how the tests reach it at small sizes.
-  if (elementCount <= vrdx::kSmallSortMaxElements && ForcedConfigIndex() < 0 && SmallSortEnabled()) {
+  if (plan.oneWorkgroup) {
     for (uint32_t s = 1; s < 14; ++s) StampSame(pool, query + s, query + 0);
     EnqueueCheck(sorter, "small_sort_kernel",
                  vrdx::LaunchSmallSort(stream, atomicRank, keys, values, elementCount, countPtr,
@@ -407,34 +476,13 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   }
 
   // (behind the empty sort and the one-workgroup sort above: neither touches the scratch arrays)
-  if (!vrdx::LayoutFits(layout, elementCount)) {
-    // EVERY sort of the general path is checked, not only those with a plan in front: the layout depends on the tile plan, and the
-    // measurement knobs (VRDX_TAIL_SPLIT, VRDX_EVEN_SPLIT, VRDX_TILE_CONFIG) can select plans the offline sweep of
-    // tests/native/layout_check.cpp never saw.  Tiles of the kernel's full capacity without block rows fit for every N
-    // (2 (tiles - 1) KiB <= (P - 1) KiB from 8192 keys per tile up); smaller tiles cannot be helped: the scratch arrays
-    // must not leave the caller's allocation, so that sort is refused and says so (VRDX_HIP_STATUS_ENQUEUE_REFUSED).
-    tilePlan = vrdx::PlanTiles(elementCount, (uint32_t)sorter->computeUnits, (uint32_t)vrdx::kTileConfigs[configIndex].threads,
-                               (uint32_t)vrdx::kTileConfigs[configIndex].keysPerThread,
-                               (uint32_t)vrdx::kTileConfigs[configIndex].subTiles, false, false, 0);
-    blockSums = false;
-    layout = vrdx::MakeLayout(elementCount, sorter->minStorageBufferOffsetAlignment, tilePlan.tiles,
-                              (uint64_t)reinterpret_cast<uintptr_t>(storage), false, 0);
-    if (!vrdx::LayoutFits(layout, elementCount)) {
-      EnqueueCheck(sorter, "storage layout (status rows do not fit the reference's partition-histogram area)", hipErrorInvalidValue);
-      return;
-    }
+  if (!plan.fits) {
+    // every slot of the timestamp contract is recorded, like in the empty sort: a caller that reads the pool after a
+    // refused sort must not wait on events that never were
+    for (uint32_t s = 1; s < 15; ++s) StampSame(pool, query + s, query + 0);
+    EnqueueCheck(sorter, "storage layout (status rows do not fit the reference's partition-histogram area)", hipErrorInvalidValue);
+    return;
   }
-  // Clear count / plan / failure word and the 4x256 global histogram (reference :382) in one fill of 4112 bytes; status
-  // region 0 is zeroed by the histogram kernel behind it.  Indirect: also copy the device-side count to where the reference keeps
-  // it (:368-379); the kernels themselves read it straight from the caller's buffer.  (Direct: the
-  // count travels as a kernel argument, the slot stays 0 -- storage contents are scratch.)
-  EnqueueCheck(sorter, "hipMemsetAsync(state)", hipMemsetAsync(storage, 0, layout.clearBytes, stream));
-  if (countPtr != nullptr)
-    EnqueueCheck(sorter, "hipMemcpyAsync(count)",
-                 hipMemcpyAsync(storage + layout.countOffset, countPtr, sizeof(uint32_t), hipMemcpyDeviceToDevice,
-                                stream));
-  Stamp(pool, query + 1, stream);
-
   uint32_t* const globalHistogram = reinterpret_cast<uint32_t*>(storage + layout.histogramOffset);
   uint32_t* const status = reinterpret_cast<uint32_t*>(storage + layout.statusOffset);
   uint32_t* const tickets = reinterpret_cast<uint32_t*>(storage + layout.ticketOffset);
@@ -442,6 +490,47 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   uint32_t* const keysScratch = reinterpret_cast<uint32_t*>(storage + layout.inoutOffset);
   uint32_t* const valuesScratch = reinterpret_cast<uint32_t*>(storage + layout.valuesOffset);
   const uint32_t statusRows = (uint32_t)layout.statusRows;
+
+  // the MSD plan's arguments: spine (prefixes over the tiles, bucket table, verdict), scatter by the window bits, one
+  // workgroup per bucket; the prologue and the histogram kernel take the same structure
+  vrdx::MsdArgs m;
+  std::memset(&m, 0, sizeof(m));
+  if (msdBits != 0) {
+    m.keysCaller = keys;
+    m.keysScratch = keysScratch;
+    m.valuesCaller = keyValue ? values : nullptr;
+    m.valuesScratch = keyValue ? valuesScratch : nullptr;
+    m.maxCount = elementCount;
+    m.countPtr = countPtr;
+    m.histogramTable = globalHistogram;
+    m.tileCounts = reinterpret_cast<uint32_t*>(storage + layout.msdCountsOffset);
+    m.bucketCount = reinterpret_cast<uint32_t*>(storage + layout.msdBucketOffset);
+    m.bucketBase = m.bucketCount + ((size_t)1 << msdBits);
+    m.overflowWord = reinterpret_cast<uint32_t*>(storage + VRDX_OFF_MSD_OVERFLOW);
+    m.planWord = reinterpret_cast<uint32_t*>(storage + VRDX_OFF_PLAN);
+    m.bits = msdBits;
+    m.cap = msdCap;
+    m.tiles = msdTiles;
+    m.tileKeys = msdTileKeys;
+    m.statusClear = storage + layout.statusClearOffset;
+    m.statusVecs = (uint32_t)(layout.statusClearBytes / 16u);
+    m.tickets = tickets;
+    m.declinedPlans = sorter->declinedPlans;
+    sorter->plansRecorded.fetch_add(1u, std::memory_order_relaxed);
+  }
+
+  // Clear count / plan / failure word and the 4x256 global histogram (reference :382) in one fill of 4112 bytes; status
+  // region 0 is zeroed by the histogram kernel behind it.  Indirect: also copy the device-side count to where the reference keeps
+  // it (:368-379); the kernels themselves read it straight from the caller's buffer.  (Direct: the
+  // count travels as a kernel argument, the slot stays 0 -- storage contents are scratch.)
+  // (With the MSD plan recorded the fill also covers the plan's bucket sizes, 4-8 KiB behind the table: its histogram kernel
+  // adds them up.)
+  EnqueueCheck(sorter, "hipMemsetAsync(state)", hipMemsetAsync(storage, 0, layout.clearBytes, stream));
+  if (countPtr != nullptr)
+    EnqueueCheck(sorter, "hipMemcpyAsync(count)",
+                 hipMemcpyAsync(storage + layout.countOffset, countPtr, sizeof(uint32_t), hipMemcpyDeviceToDevice,
+                                stream));
+  Stamp(pool, query + 1, stream);
 
   // upsweep of all four passes at once
   {
@@ -459,13 +548,10 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     static const int forcedGrid = TuningKnob("VRDX_HIST_GRID");  // tools/hist_grid.sh
     if (forcedGrid > 0) grid = (uint32_t)forcedGrid;
     if (msdBits != 0) {
-      // the MSD plan's form: top-bits counts per tile of 32768 keys (a workgroup takes whole tiles)
+      // the MSD plan's form: window-bits counts per tile of up to 32768 keys (a workgroup takes whole tiles); the spine
+      // kernel clears status region 0
       if (forcedGrid <= 0) grid = std::min<uint32_t>(msdTiles, cap);
-      EnqueueCheck(sorter, "histogram_msd_kernel",
-                   vrdx::LaunchHistogramMsd(stream, grid, keys, elementCount, countPtr, globalHistogram, tickets,
-                                            storage + layout.statusClearOffset, 0u /* the spine kernel clears status region 0 */,
-                                            reinterpret_cast<uint32_t*>(storage + layout.msdCountsOffset), msdTiles, msdBits,
-                                            msdTileKeys));
+      EnqueueCheck(sorter, "histogram_msd_kernel", vrdx::LaunchHistogramMsd(stream, grid, m));
     } else {
       EnqueueCheck(sorter, "histogram_kernel",
                    vrdx::LaunchHistogram(stream, grid, keys, elementCount, countPtr, globalHistogram, tickets,
@@ -528,42 +614,16 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
 #endif
     return args;
   };
-  uint32_t msdFused = 0;  // how many of the plan's launches double as the fallback's first passes (0 | 1: the scatter | 2: and the buckets)
+  const uint32_t msdFused = plan.msdFused;  // how many of the plan's launches double as the fallback's first passes (PlanSort)
   // The MSD plan, recorded in front of the passes: spine (prefixes over the tiles, bucket table,
-  // verdict), scatter by the top bits, one workgroup per bucket.  The passes behind return on the verdict word.
+  // verdict), scatter by the window bits, one workgroup per bucket.  The passes behind return on the verdict word.
   if (msdBits != 0) {
-    vrdx::MsdArgs m;
-    std::memset(&m, 0, sizeof(m));
-    m.keysCaller = keys;
-    m.keysScratch = keysScratch;
-    m.valuesCaller = keyValue ? values : nullptr;
-    m.valuesScratch = keyValue ? valuesScratch : nullptr;
-    m.maxCount = elementCount;
-    m.countPtr = countPtr;
-    m.histogramTable = globalHistogram;
-    m.tileCounts = reinterpret_cast<uint32_t*>(storage + layout.msdCountsOffset);
-    m.bucketBase = reinterpret_cast<uint32_t*>(storage + layout.msdBucketOffset);
-    m.bucketCount = m.bucketBase + ((size_t)1 << msdBits);
-    m.overflowWord = reinterpret_cast<uint32_t*>(storage + VRDX_OFF_MSD_OVERFLOW);
-    m.planWord = reinterpret_cast<uint32_t*>(storage + VRDX_OFF_PLAN);
-    m.bits = msdBits;
-    m.cap = msdCap;
-    m.tiles = msdTiles;
-    m.tileKeys = msdTileKeys;
-    m.statusClear = storage + layout.statusClearOffset;
-    m.statusVecs = (uint32_t)(layout.statusClearBytes / 16u);
     // Timestamps: the plan's own three stages take the names they have in the reference -- slot 2 "upsweep" = the
     // histogram, 3 "spine", 4 "downsweep" = the scatter -- and the bucket sorts are pass 1's "upsweep" (slot 5, like the
     // eight-bit plan's); the four returning passes share the slots behind.
     Stamp(pool, query + 2, stream);
     EnqueueCheck(sorter, "spine_msd_kernel", vrdx::LaunchSpineMsd(stream, m));
     Stamp(pool, query + 3, stream);
-    // The scatter launch is ALSO pass 0 of the fallback and the bucket launch pass 1 (one branch on the verdict, on the
-    // device): only passes 2 and 3 remain as launches that return when the plan runs.  The fused kernels exist for the
-    // geometry the recorder selects at these sizes (ConfigIndex: the two-sub-tile kernel).
-    // Keys-only sorts (the key+value form measured slower than the launches it saves, vrdx_kernels.hip).
-    // Buckets of the half-size kernel (512 threads; the passes' bodies need 1024): only the scatter launch has a second role.
-    msdFused = !keyValue && configIndex == kCfg1024x32x2 && TuningKnob("VRDX_MSD_FUSED") != 0 ? (msdCap == vrdx::kMsdCapKeys ? 2u : 1u) : 0u;
     if (msdFused >= 1)
       EnqueueCheck(sorter, "msd_scatter_or_pass0_kernel", vrdx::LaunchMsdFused(stream, false, keyValue, m, passArgs(0), tilePlan.tiles));
     else
@@ -669,8 +729,9 @@ VkResult vrdxCreateSorter(const VrdxSorterCreateInfo* pCreateInfo, VrdxSorter* p
   if (e == hipSuccess) e = vrdx::PrepareSmallSort();
   if (e == hipSuccess) e = vrdx::PrepareBucketSort();
   if (e == hipSuccess) e = vrdx::PrepareMsd();
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sorter->stickyStatus), sizeof(uint32_t));
-  if (e == hipSuccess) e = hipMemset(sorter->stickyStatus, 0, sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sorter->stickyStatus), 2 * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMemset(sorter->stickyStatus, 0, 2 * sizeof(uint32_t));
+  if (e == hipSuccess) sorter->declinedPlans = sorter->stickyStatus + 1;
   if (e == hipSuccess) {
     // Ranking mode: the single-atomic form needs a hardware property the ISA manual does not
     // promise, so it is verified here, once, on this very device; VRDX_RANK=ballot|atomic|auto.
@@ -946,35 +1007,47 @@ void vrdxHipDescribePlan(VrdxSorter sorter, uint32_t elementCount, int keyValue,
   const bool kv = keyValue != 0;
   const uint32_t fourPasses = kv ? 68u : 36u;  // 4 (histogram) + 4 x (read + write)
   const uint32_t twoTrips = kv ? 36u : 20u;    // 4 (histogram) + scatter (read + write) + buckets (read + write)
-  const bool atomicRank = sorter->atomicRank.load(std::memory_order_relaxed);
-  const bool adaptive = ForcedConfigIndex() < 0;
+  // the recorder's own planning function (storage address 0: the alignment at which the least fits)
+  const SortPlan plan = PlanSort(sorter, kv, elementCount, 0);
   info->fallbackBytesPerElement = fourPasses;
-  if (elementCount <= vrdx::kSmallSortMaxElements && adaptive && SmallSortEnabled()) {
+  info->launches = plan.launches;
+  if (plan.oneWorkgroup) {
     info->plan = VRDX_HIP_PLAN_ONE_WORKGROUP;
     info->bytesPerElement = info->fallbackBytesPerElement = kv ? 16u : 8u;
-    info->launches = 1;
-    return;
-  }
-  uint32_t msdCap = 0;
-  const uint32_t hybridCap = adaptive ? HybridCapacity(atomicRank, elementCount) : 0u;
-  const uint32_t msdBits = adaptive && hybridCap == 0 ? MsdBits(atomicRank, kv, elementCount, hybridCap, &msdCap) : 0u;
-  if (msdBits != 0) {
+  } else if (plan.msdBits != 0) {
     info->plan = VRDX_HIP_PLAN_MSD;
-    info->bits = msdBits;
+    info->bits = plan.msdBits;
     info->bytesPerElement = twoTrips;
-    // histogram, spine, scatter, buckets, four returning passes (keys-only: two of them folded into the plan's launches,
-    // one with the half-size bucket kernel)
-    info->launches = kv ? 8u : (msdCap == vrdx::kMsdCapKeys ? 6u : 7u);
-  } else if (hybridCap != 0) {
+  } else if (plan.hybridCap != 0) {
     info->plan = VRDX_HIP_PLAN_HYBRID8;
     info->bits = 8;
     info->bytesPerElement = twoTrips;
-    info->launches = 6;
   } else {
     info->plan = VRDX_HIP_PLAN_FOUR_PASSES;
     info->bytesPerElement = fourPasses;
-    info->launches = 5;
   }
+}
+
+uint32_t vrdxHipReadPlanVerdict(VkCommandBuffer commandBuffer, VkBuffer storageBuffer, VkDeviceSize storageOffset) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(commandBuffer);
+  uint32_t word = 0xFFFFFFFFu;
+  if (hipMemcpyAsync(&word, BufferAddress(storageBuffer, storageOffset) + VRDX_OFF_PLAN, sizeof(word), hipMemcpyDeviceToHost,
+                     stream) != hipSuccess)
+    return 0xFFFFFFFFu;
+  if (hipStreamSynchronize(stream) != hipSuccess) return 0xFFFFFFFFu;
+  return word & vrdx::kMsdVerdictMask;  // (the MSD plan's scatter also notes its window's shift there, bits 8-13)
+}
+
+VkResult vrdxHipReadPlanCounters(VrdxSorter sorter, VkCommandBuffer commandBuffer, uint32_t* pRecorded, uint32_t* pDeclined) {
+  if (sorter == nullptr || sorter->declinedPlans == nullptr) return VK_ERROR_INITIALIZATION_FAILED;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(commandBuffer);
+  uint32_t declined = 0;
+  if (hipMemcpyAsync(&declined, sorter->declinedPlans, sizeof(declined), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+      hipStreamSynchronize(stream) != hipSuccess)  // (the copy targets this stack frame: never return while it may be in flight)
+    return VK_ERROR_DEVICE_LOST;
+  if (pRecorded != nullptr) *pRecorded = sorter->plansRecorded.load(std::memory_order_relaxed);
+  if (pDeclined != nullptr) *pDeclined = declined;
+  return VK_SUCCESS;
 }
 
 const char* vrdxHipVersionString(void) {

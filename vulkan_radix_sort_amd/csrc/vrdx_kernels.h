@@ -127,21 +127,57 @@ hipError_t LaunchBucketSort(hipStream_t stream, bool keyValue, bool atomicRank, 
 
 // The MSD plan of large sorts (round 5; vrdx_kernels.hip, "MSD plan"): THREE ranking steps of 10-11 bits instead of four
 // of 8, and TWO trips of the data through memory instead of four --
-//   histogram_msd_kernel  the byte histograms (for the fallback) and, per tile of kMsdTileKeys keys, the counts of the
-//                         keys' top `bits` bits as 16-bit numbers (tileCounts);
-//   spine_msd_kernel      turns them, in place, into exclusive prefixes over the tiles and leaves every bucket's base and
-//                         size (bucketBase / bucketCount); a bucket beyond `cap` elements sets *overflowWord;
-//   scatter_msd_kernel    one stable scatter by those bits, caller -> scratch: no ticket, no look-back, no status words --
+//   histogram_msd_kernel  CHOOSES THE WINDOW (round 6): from 64 keys sampled evenly over the input (first and last key
+//                         included; every workgroup takes the same sample and reaches the same answer) it takes the bits in
+//                         which they differ and puts the 2^bits-wide window right below their common prefix -- keys of 24
+//                         bits, dense sorted ids, anything narrow then spread over all the buckets like uniform 32-bit keys do
+//                         over the top bits -- and predicts what the plan cannot take anyway (MsdMode below).  Then the byte
+//                         histograms (for the fallback) and, per tile of tileKeys keys, the counts of the keys' window bits as
+//                         16-bit numbers (tileCounts); the bucket sizes; a key that breaks the sampled prefix raises the
+//                         overflow word -- the sample is the guess, the count stays the proof;
+//   spine_msd_kernel      turns the counts, in place, into exclusive prefixes over the tiles and leaves every bucket's base;
+//                         a bucket beyond `cap` elements sets *overflowWord;
+//   scatter_msd_kernel    one stable scatter by the window bits, caller -> scratch: no ticket, no look-back, no status words --
 //                         a tile's bases are bucketBase[d] + its row of prefixes;
-//   bucket_sort2_kernel   one workgroup per bucket sorts it by the remaining 21-22 bits in TWO stable passes of up to
-//                         11 bits inside its LDS, scratch -> caller.
+//   bucket_sort2_kernel   one workgroup per bucket sorts it by the bits below the window (none, one or two stable passes of
+//                         up to 11 bits) inside its LDS, scratch -> caller.
 // All of it with wave-private counters of 16 bits, two to a word.  The device decides (the overflow word): with a bucket
-// beyond the capacity the last two return at once and the four passes recorded behind them run.
+// beyond the capacity or a key outside the prefix the last two return at once and the four passes recorded behind them run.
 constexpr uint32_t kMsdTileKeys = 32768;   // a scatter tile's capacity: 1024 threads x 32 keys
 constexpr uint32_t kMsdMaxTiles = 2048;    // spine_msd_kernel: 64 chunks of at most 32 rows
 constexpr uint32_t kMsdCapKeys = 36864;    // bucket capacity, keys-only: 1024 threads x 36 keys (144 KiB of staging)
 constexpr uint32_t kMsdCapKeyValue = 36864;  // the same for pairs: keys and values take turns in the staging buffer
 constexpr uint32_t kMsdHalfCap = 18432;    // buckets of the half-size bucket kernel: 512 threads x 36 elements (72 KiB of staging), two workgroups per CU
+// What the histogram kernel decides travels in the OVERFLOW WORD itself (VRDX_OFF_MSD_OVERFLOW), so that every launch behind it learns
+// "is the plan turned down, where is the window, what kind of input is it" from the one word it reads anyway -- a second
+// word would be a second dependent memory round trip in front of the first key load of every workgroup:
+//   bits 0-7   non-zero = the plan is turned down (kMsdDecline*: by the spine, the histogram kernel, the prologue)
+//   bits 8-13  shift: the scatter ranks by (key >> shift) & (2^bits - 1); the bucket kernel sorts the `shift` bits below
+//   bits 16-17 MsdMode
+// The scatter passes the shift on in the verdict word (kMsdVerdict* | shift << 8) for the same reason.
+constexpr uint32_t kMsdDeclineMask = 0xFFu;
+constexpr uint32_t kMsdDeclineBucket = 1u;  // spine: a bucket holds more than the capacity
+constexpr uint32_t kMsdDeclinePrefix = 2u;  // histogram: a key outside the sampled prefix / not the sampled key (all sampled keys identical)
+constexpr uint32_t kMsdDeclineSample = 4u;  // histogram: the sample rules the plan out
+constexpr uint32_t kMsdShiftShift = 8u, kMsdShiftMask = 63u, kMsdModeShift = 16u, kMsdModeMask = 3u;
+enum MsdMode : uint32_t {
+  kMsdModePlan = 0,       // counts per tile and window value; spine, scatter, buckets
+  kMsdModeDeclined = 1,   // the sample shows a bucket the plan cannot hold (few distinct values, keys of fewer bits than the
+                          // window over more elements than fit): the overflow word is raised at once, the four byte tables
+                          // are all that is counted and the spine kernel returns
+  kMsdModeIdentical = 2,  // every sampled key is the same: the histogram kernel checks that ALL are (or raises the overflow
+                          // word); if so the input is sorted as it stands and every launch behind returns (verdict 4)
+};
+// The sample: one key per lane of wave 0 of every histogram workgroup, evenly spread, first and last key included.  (Round 6
+// first took it in a one-workgroup kernel in place of the fill in front of the sort -- 4096 keys: an 11.5 us kernel, 1024 keys:
+// 5.9 us, where the fill takes 4.3 and the histogram kernel cannot start before it has ended.  64 lines re-read by every
+// workgroup are nothing next to the 512 KiB each of them streams.)
+constexpr uint32_t kMsdSampleKeys = 64;
+constexpr uint32_t kMsdSampleSkew = 8;      // sampled keys in one bucket (expected: 1 / 16 or less) from which the plan is turned down unseen
+// verdict word (VRDX_OFF_PLAN), low byte, of the MSD plan; the passes behind it return on either
+constexpr uint32_t kMsdVerdictMask = 0xFFu;
+constexpr uint32_t kMsdVerdictRuns = 3;      // scatter and bucket launches do the sort (bits 8-13: the window's shift)
+constexpr uint32_t kMsdVerdictSorted = 4;    // all keys identical: nothing to do
 struct MsdArgs {
   uint32_t* keysCaller;
   uint32_t* keysScratch;
@@ -149,12 +185,12 @@ struct MsdArgs {
   uint32_t* valuesScratch;     // KV only
   uint32_t maxCount;           // element count (direct) or upper bound (indirect)
   const uint32_t* countPtr;    // device-side element count (indirect) or nullptr
-  const uint32_t* histogramTable;  // uint[4][256]; the spine reads row 3
+  uint32_t* histogramTable;    // uint[4][256]
   uint32_t* tileCounts;        // [tiles][2^bits / 2] words = pairs of 16-bit numbers: counts, then prefixes over the tiles
   uint32_t* bucketBase;        // [2^bits]
-  uint32_t* bucketCount;       // [2^bits]
-  uint32_t* overflowWord;      // VRDX_OFF_MSD_OVERFLOW in the storage: non-zero = some bucket exceeds cap
-  uint32_t* planWord;          // VRDX_OFF_PLAN: the scatter writes 3 when the plan applies (the passes then return)
+  uint32_t* bucketCount;       // [2^bits]: zeroed by the prologue, added up by the histogram kernel
+  uint32_t* overflowWord;      // VRDX_OFF_MSD_OVERFLOW in the storage: non-zero = the plan is turned down
+  uint32_t* planWord;          // VRDX_OFF_PLAN: the scatter writes kMsdVerdictRuns / kMsdVerdictSorted (the passes then return)
   uint32_t bits;               // 10 | 11
   uint32_t cap;                // elements a bucket may hold
   uint32_t tiles;              // ceil(maxCount / tileKeys) <= kMsdMaxTiles
@@ -163,12 +199,11 @@ struct MsdArgs {
   // bandwidth to spare, instead of by the histogram kernel (which it cost 1.9 us at 2^25, round 4)
   void* statusClear;
   uint32_t statusVecs;
+  uint32_t* tickets;           // zeroed by the histogram kernel
+  uint32_t* declinedPlans;     // the sorter's counter of plans the device turned down (vrdxHipReadPlanCounters), or nullptr
 };
 hipError_t PrepareMsd();
-hipError_t LaunchHistogramMsd(hipStream_t stream, uint32_t grid, const uint32_t* keys, uint32_t maxCount,
-                              const uint32_t* countPtr, uint32_t* globalHistogram, uint32_t* tickets, void* statusClear,
-                              uint32_t statusClearBytes, uint32_t* tileCounts, uint32_t tiles, uint32_t bits,
-                              uint32_t tileKeys);
+hipError_t LaunchHistogramMsd(hipStream_t stream, uint32_t grid, const MsdArgs& args);
 hipError_t LaunchSpineMsd(hipStream_t stream, const MsdArgs& args);
 hipError_t LaunchScatterMsd(hipStream_t stream, bool keyValue, const MsdArgs& args);
 hipError_t LaunchBucketSort2(hipStream_t stream, bool keyValue, const MsdArgs& args);

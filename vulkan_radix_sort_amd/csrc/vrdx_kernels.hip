@@ -1104,7 +1104,7 @@ __device__ __forceinline__ void OnesweepBody(const OnesweepArgs a) {
     if (a.hybridCap != 0 && a.pass != 0 && *a.planWord == 1u) return;
   }
   // the MSD plan (recorded in front of launch 0) has taken the sort: nothing left for the passes
-  if (a.planInFront != 0 && *a.planWord == 3u) return;
+  if (a.planInFront != 0 && (*a.planWord & kMsdVerdictMask) >= kMsdVerdictRuns) return;
 
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   uint32_t key[KPT];
@@ -1363,7 +1363,7 @@ __device__ __forceinline__ void OnesweepPairBody(const OnesweepArgs a) {
 #endif
   VRDX_STAMP(0);
 
-  if (a.planInFront != 0 && *a.planWord == 3u) return;  // the MSD plan has taken the sort (see onesweep_kernel)
+  if (a.planInFront != 0 && (*a.planWord & kMsdVerdictMask) >= kMsdVerdictRuns) return;  // the MSD plan has taken the sort (see onesweep_kernel)
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   const PassCounts<THREADS> passCounts = LoadPassCounts<THREADS>(a.histogramTable, tid);
   if (tid == 0) misc[0] = (VRDX_ABLATE & 8) ? blockIdx.x : atomicAdd(a.ticketCur, 1u);
@@ -1832,8 +1832,17 @@ __device__ __forceinline__ void StaticFor(F&& body) {
 // served in ascending lane order whatever they add (lds_order_check_packed_kernel verifies exactly this shape), and a
 // wave's <= 2304 keys cannot carry out of a half.  Uniform slots (sorted or constant input) are ranked by one lane adding
 // 64; the test runs only in chunks whose first slot looks the part (see RankAtomic).  Ranks come two to a register.
+// The digit is the `width` bits of the key from bit `shift` up (both wave-uniform, width >= 1): its counter word and its
+// half of the word are bit fields of the key themselves -- one v_bfe_u32 each, with the run-time window of round 6 as with
+// constants (as `(key >> shift) & mask` a run-time mask cost the bucket kernel 11 us of 108 at 2^25).
+__device__ __forceinline__ uint32_t DigitWord(uint32_t key, uint32_t shift, uint32_t width) {
+  return __builtin_amdgcn_ubfe(key, shift + 1u, width - 1u);  // digit >> 1
+}
+__device__ __forceinline__ uint32_t DigitHalf(uint32_t key, uint32_t shift) {
+  return __builtin_amdgcn_ubfe(key, shift, 1u) * 16u;  // (digit & 1) * 16
+}
 template <int KPT, bool DYN>
-__device__ __forceinline__ void RankPacked16(const uint32_t (&key)[KPT], uint32_t shift, uint32_t mask, uint32_t* myRow,
+__device__ __forceinline__ void RankPacked16(const uint32_t (&key)[KPT], uint32_t shift, uint32_t width, uint32_t* myRow,
                                              int lane, uint32_t (&out)[KPT / 2], uint32_t slots = KPT) {
   constexpr int CHUNK = (!DYN && KPT % 8 == 0) ? 8 : 4;
   static_assert(KPT % CHUNK == 0 && CHUNK % 2 == 0, "whole chunks of pairs");
@@ -1841,12 +1850,12 @@ __device__ __forceinline__ void RankPacked16(const uint32_t (&key)[KPT], uint32_
     constexpr int base = decltype(chunk)::value;
     if (DYN && (uint32_t)base >= slots) return false;
     uint32_t r[CHUNK];
-    const uint32_t probe = (key[base] >> shift) & mask;
+    const uint32_t probe = __builtin_amdgcn_ubfe(key[base], shift, width);
     const bool watch = __popcll(__ballot(probe != (uint32_t)__builtin_amdgcn_readfirstlane(probe))) <= 48;  // wave-uniform
     if (watch) {
 #pragma unroll
       for (int c = 0; c < CHUNK; ++c) {
-        const uint32_t d = (key[base + c] >> shift) & mask;
+        const uint32_t d = __builtin_amdgcn_ubfe(key[base + c], shift, width);
         const uint32_t sh = (d & 1u) * 16u;
         const bool uniform = __ballot(d != (uint32_t)__builtin_amdgcn_readfirstlane(d)) == 0ull;  // wave-uniform
         uint32_t old = 0;
@@ -1859,10 +1868,9 @@ __device__ __forceinline__ void RankPacked16(const uint32_t (&key)[KPT], uint32_
     } else {
 #pragma unroll
       for (int c = 0; c < CHUNK; ++c) {
-        const uint32_t d = (key[base + c] >> shift) & mask;
-        const uint32_t sh = (d & 1u) * 16u;
-        const uint32_t old =
-            __hip_atomic_fetch_add(&myRow[d >> 1], 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t sh = DigitHalf(key[base + c], shift);
+        const uint32_t old = __hip_atomic_fetch_add(&myRow[DigitWord(key[base + c], shift, width)], 1u << sh, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_WORKGROUP);
         r[c] = (old >> sh) & 0xFFFFu;
       }
     }
@@ -1951,7 +1959,7 @@ __device__ __forceinline__ void ColumnPairBasesFrom(uint32_t* counters, uint32_t
 // ranks -> physical staging slots, in place: slot = StagingSlot(row[digit] + rank).  Reads only; the staging buffer may
 // alias the counters once every wave has been through here (the caller's barrier).
 template <int KPT, uint32_t STAGE, bool DYN>
-__device__ __forceinline__ void PositionsPacked16(const uint32_t (&key)[KPT], uint32_t shift, uint32_t mask,
+__device__ __forceinline__ void PositionsPacked16(const uint32_t (&key)[KPT], uint32_t shift, uint32_t width,
                                                   const uint32_t* myRow, uint32_t (&rankThenSlot)[KPT / 2],
                                                   uint32_t slots = KPT) {
   constexpr int CHUNK = (!DYN && KPT % 8 == 0) ? 8 : 4;
@@ -1960,13 +1968,12 @@ __device__ __forceinline__ void PositionsPacked16(const uint32_t (&key)[KPT], ui
     if (DYN && (uint32_t)base >= slots) return false;
     uint32_t w[CHUNK];
 #pragma unroll
-    for (int c = 0; c < CHUNK; ++c) w[c] = myRow[((key[base + c] >> shift) & mask) >> 1];
+    for (int c = 0; c < CHUNK; ++c) w[c] = myRow[DigitWord(key[base + c], shift, width)];
 #pragma unroll
     for (int c = 0; c < CHUNK; ++c) {
       const int i = base + c;
-      const uint32_t d = (key[i] >> shift) & mask;
       const uint32_t r = (rankThenSlot[i / 2] >> (16 * (i % 2))) & 0xFFFFu;
-      w[c] = StagingSlot<STAGE>(((w[c] >> ((d & 1u) * 16u)) & 0xFFFFu) + r);
+      w[c] = StagingSlot<STAGE>(((w[c] >> DigitHalf(key[i], shift)) & 0xFFFFu) + r);
     }
 #pragma unroll
     for (int c = 1; c < CHUNK; c += 2) {
@@ -1977,56 +1984,149 @@ __device__ __forceinline__ void PositionsPacked16(const uint32_t (&key)[KPT], ui
   });
 }
 
+// ---- the window of the MSD plan ------------------------------------------------------------------------
+// The scatter digit used to be the keys' top BITS bits, whatever the keys: 24-bit keys, dense ascending or descending ids,
+// anything whose top bits are constant then fell into a handful of buckets, the plan was turned down and the four passes ran
+// (every pattern of BASELINE config 4 in round 5).  Since round 6 histogram_msd_kernel first looks at 64 keys, evenly spread
+// over the input with the first and the last one among them (wave 0 of EVERY workgroup takes the same sample and reaches the
+// same conclusion; workgroup 0 publishes it in the overflow word): the bits in which they all agree are the (guessed) common
+// prefix, the window is the BITS bits right below it, and the bucket kernel sorts whatever is left below the window.  Uniform
+// 32-bit keys have no common prefix and get the window they always had.  The sample is only the guess: every key is checked
+// against the prefix and raises the overflow word if it breaks it, exactly like the spine does for a bucket that is too large.
+// (For a monotone input the first and the last key are the extremes, so the guess is exact; for keys drawn at random a bit
+// that varies in one key in ten is missed once in a thousand sorts -- and such keys do not spread over the window's buckets
+// anyway.)
+//
+// The same sample predicts two cases the plan cannot take, so that they do not pay for the attempt (MsdMode): all sampled
+// keys identical -> only the four byte tables are counted while every key is compared with the sampled one, and if all ARE
+// identical nothing needs sorting (verdict 4); a bucket that is certainly too large -- fewer varying bits than the window over
+// more elements than the buckets hold, or kMsdSampleSkew of the 64 sampled keys in one bucket -> the overflow word is raised
+// at once and the four byte tables are all that is counted.  In both the spine kernel returns at once.
+__device__ __forceinline__ uint32_t WaveOr(uint32_t v) {
+  int x = (int)v;
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);   // row_shr:1
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);   // row_shr:2
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);   // row_shr:4
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // row_shr:8
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return (uint32_t)__builtin_amdgcn_readlane(x, 63);               // lane 63 holds the OR over the wave
+}
+
 // ---- histogram_msd_kernel ---------------------------------------------------------------------------
 // histogram_kernel (same pipeline: two groups of four 16-byte loads per lane in flight, all workgroups inside one window of
-// the input) with the fourth table replaced: instead of byte 3 it counts the keys' top BITS bits, PER TILE of 32768 keys
-// (= two groups), in 2^BITS bins x TC replicas of 32 KiB in all, and after each tile writes the 2^BITS counts out as
-// 16-bit numbers (a tile holds 32768 keys: 0x8000 fits), adds them up into byte 3's histogram (4 or 8 bins each) and
-// clears them.  A wave whose 64 keys share their top bits (sorted, constant, narrow inputs: exactly the inputs this plan
-// will turn down) would serialise 16-way on TC replicas: one lane adds 64 instead.
+// the input) with a fifth table: the keys' WINDOW bits (MsdWindow: (key >> shift) & (2^BITS - 1), the prologue's choice),
+// counted PER TILE of up to 32768 keys in 2^BITS bins x TC replicas of 32 KiB in all; after each tile the 2^BITS counts go
+// out as 16-bit numbers (a tile holds at most 32768 keys: 0x8000 fits), are added to the workgroup's bucket sizes and
+// cleared.  A wave whose 64 keys share their window bits would serialise 16-way on TC replicas: one lane adds 64 instead.
+// Three forms of the loop, chosen by the window (uniform for the whole launch):
+//   TOP       the window is the top BITS bits (uniform 32-bit keys: round 5's kernel): byte 3's table is not counted, it
+//             follows from the bucket sizes;
+//   PREFIXED  the window lies below a common prefix: byte 3 has a table of its own (the fallback needs all four if a key
+//             breaks the prefix), and every key is XOR-ed against the reference key -- a difference above the window raises
+//             the overflow word;
+//   TABLES    the prologue has turned the plan down, or found every sampled key identical: the four byte tables only,
+//             like histogram_kernel; in the second case any key that differs from the reference raises the overflow word.
 constexpr uint32_t kMsdTopBinWords = 8192;  // 32 KiB: 1024 bins x 8 replicas | 2048 x 4
 
-constexpr uint32_t HistMsdLdsBytes(uint32_t copies) { return (3u * 256u * copies + kMsdTopBinWords + 256u) * 4u; }
+constexpr uint32_t HistMsdByte3Copies(uint32_t copies) { return copies < 16u ? copies : 16u; }
+constexpr uint32_t HistMsdLdsBytes(uint32_t copies, uint32_t bits) {
+  return (3u * 256u * copies + kMsdTopBinWords + (1u << bits) + 256u * HistMsdByte3Copies(copies) + 4u) * 4u;
+}
 
 template <uint32_t COPIES, uint32_t BITS>
-__global__ __launch_bounds__(kHistThreads) void histogram_msd_kernel(const uint32_t* __restrict__ keys, uint32_t maxCount,
-                                                                      const uint32_t* countPtr,
-                                                                      uint32_t* __restrict__ globalHistogram,
-                                                                      uint32_t* __restrict__ tickets,
-                                                                      u32x4* __restrict__ statusClear, uint32_t statusVecs,
-                                                                      uint32_t* __restrict__ tileCounts, uint32_t tiles,
-                                                                      uint32_t rows) {
-  // rows: a tile is `rows` rows of 1024 sixteen-byte vectors = rows x 4096 keys (1 ... 8: the scatter's tiles of 4 ... 32 slots
-  // of 64 keys per wave, MsdTilePlan in vrdx_api.cpp)
+__global__ __launch_bounds__(kHistThreads) void histogram_msd_kernel(MsdArgs a) {
+  // a tile is `rows` rows of 1024 sixteen-byte vectors = rows x 4096 keys (1 ... 8: the scatter's tiles of 4 ... 32 slots
+  // of 64 keys per wave, MsdTileKeysFor in vrdx_layout.h)
   static_assert(kHistThreads == 1024, "a row of vectors per load instruction");
   constexpr uint32_t D = 1u << BITS;
-  constexpr uint32_t TC = kMsdTopBinWords / D;        // replicas of a top-bits bin
+  constexpr uint32_t TC = kMsdTopBinWords / D;        // replicas of a window bin
   constexpr uint32_t kByteWords = 3u * VRDX_RADIX * COPIES;
-  constexpr uint32_t PER_BYTE = D / 512u;             // words (pairs of bins) per value of byte 3: 2 | 4
+  constexpr uint32_t C3 = HistMsdByte3Copies(COPIES); // replicas of byte 3's own table (PREFIXED)
+  constexpr uint32_t PER_BYTE = D / 256u;             // buckets per value of byte 3 when the window is at the top: 4 | 8
+  static_assert(kMsdTopBinWords >= VRDX_RADIX * COPIES, "TABLES: byte 3's table takes the window bins' place");
+  enum : uint32_t { TOP = 0, PREFIXED = 1, TABLES = 2 };
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* const bins = smem;                        // [3][256][COPIES]
-  uint32_t* const top = smem + kByteWords;            // [D][TC]
-  uint32_t* const byte3 = top + kMsdTopBinWords;      // [256], each word owned by one thread
+  uint32_t* const top = smem + kByteWords;            // [D][TC]; TABLES: byte 3's [256][COPIES]
+  uint32_t* const bucketSize = top + kMsdTopBinWords; // [D]: this workgroup's share of every bucket, word pairs owned by one thread
+  uint32_t* const byte3 = bucketSize + D;             // PREFIXED: [256][C3]
+  uint32_t* const verdict = byte3 + VRDX_RADIX * C3;  // [2]: wave 0's conclusion from the sample, the reference key
+  const uint32_t* const keys = a.keysCaller;
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
-  if (blockIdx.x == 0 && tid < 3) tickets[tid] = 0;
-  const uint32_t n = ElementCount(maxCount, countPtr);
+  if (blockIdx.x == 0 && tid < 3) a.tickets[tid] = 0;
+  const uint32_t n = ElementCount(a.maxCount, a.countPtr);
+  const uint32_t rows = a.tileKeys / 4096u;
+  const uint32_t tiles = a.tiles;
+  // wave 0's sample (above): in flight in front of the first tile's loads
+  static_assert(kMsdSampleKeys == 64, "one sampled key per lane of wave 0");
+  uint32_t sampled = 0;
+  if (tid < kMsdSampleKeys && n != 0u)
+    sampled = keys[(uint32_t)(((uint64_t)tid * (uint64_t)(n - 1u)) / (kMsdSampleKeys - 1u))];  // keys 0 ... n - 1
+  uint32_t ref = 0;  // key 0
 
   const uint32_t copy = tid & (COPIES - 1);
-  auto count = [&](uint32_t key) {
-#pragma unroll
-    for (uint32_t p = 0; p < 3; ++p) {
-      const uint32_t d = (key >> (8 * p)) & 0xFFu;
-      atomicAdd(&bins[(p * VRDX_RADIX + d) * COPIES + copy], 1u);
-    }
-    const uint32_t t = key >> (32u - BITS);
+  uint32_t shift = 0, mode = 0, form = TOP;  // (from `decided`, in sweep)
+  uint32_t differs = 0;  // OR of key ^ ref over this thread's keys (PREFIXED, TABLES)
+  uint32_t likeRef = 0;  // PREFIXED: this thread's keys whose byte 3 is the reference key's (nearly all: it lies in the prefix)
+  // One lane adds the whole wave's share where all its active lanes agree on the bin in ALL their NK keys (sorted, constant,
+  // narrow inputs: 64 lanes on TC replicas of one bin would serialise 8- or 16-way); one test per NK keys.
+  auto addShared = [&](auto nk, uint32_t* table, const uint32_t (&bin)[decltype(nk)::value], uint32_t replicas) {
+    constexpr uint32_t NK = decltype(nk)::value;
     const uint64_t active = __ballot(true);  // (taken HERE: inside the one-lane branch below it would be that one lane)
-    const bool uniform = __ballot(t != (uint32_t)__builtin_amdgcn_readfirstlane(t)) == 0ull;  // among the active lanes
-    if (!uniform)
-      atomicAdd(&top[t * TC + (tid & (TC - 1))], 1u);
-    else if (lane == (uint32_t)__builtin_ctzll(active))
-      atomicAdd(&top[t * TC], (uint32_t)__popcll(active));
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane(bin[0]);
+    uint32_t other = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < NK; ++i) other |= bin[i] ^ first;
+    if (__ballot(other != 0u) != 0ull) {
+#pragma unroll
+      for (uint32_t i = 0; i < NK; ++i) atomicAdd(&table[bin[i] * replicas + (tid & (replicas - 1))], 1u);
+    } else if (lane == (uint32_t)__builtin_ctzll(active)) {
+      atomicAdd(&table[first * replicas], NK * (uint32_t)__popcll(active));
+    }
   };
+  auto count = [&](auto form, auto nk, const uint32_t (&key)[decltype(nk)::value]) {
+    constexpr uint32_t FORM = decltype(form)::value;
+    constexpr uint32_t NK = decltype(nk)::value;
+#pragma unroll
+    for (uint32_t i = 0; i < NK; ++i) {
+#pragma unroll
+      for (uint32_t p = 0; p < 3; ++p) {
+        const uint32_t d = (key[i] >> (8 * p)) & 0xFFu;
+        atomicAdd(&bins[(p * VRDX_RADIX + d) * COPIES + copy], 1u);
+      }
+      if constexpr (FORM == TABLES) atomicAdd(&top[(key[i] >> 24) * COPIES + copy], 1u);
+      if constexpr (FORM != TOP) differs |= key[i] ^ ref;
+    }
+    if constexpr (FORM == PREFIXED) {
+      // byte 3 (the fallback needs its table if a key breaks the prefix): counted in a register where it is the reference
+      // key's, which it is for every key when the window ends at or below bit 24
+      uint32_t unlike = 0;
+#pragma unroll
+      for (uint32_t i = 0; i < NK; ++i) {
+        const bool like = ((key[i] ^ ref) >> 24) == 0u;
+        likeRef += like ? 1u : 0u;
+        unlike |= like ? 0u : 1u << i;
+      }
+      if (unlike != 0u) {
+#pragma unroll
+        for (uint32_t i = 0; i < NK; ++i)
+          if ((unlike >> i) & 1u) {
+            const uint32_t one[1] = {key[i] >> 24};
+            addShared(std::integral_constant<uint32_t, 1>{}, byte3, one, C3);
+          }
+      }
+    }
+    if constexpr (FORM != TABLES) {
+      uint32_t t[NK];
+#pragma unroll
+      for (uint32_t i = 0; i < NK; ++i) t[i] = FORM == TOP ? key[i] >> (32u - BITS) : (key[i] >> shift) & (D - 1u);
+      addShared(nk, top, t, TC);
+    }
+  };
+  constexpr std::integral_constant<uint32_t, 1> kOne{};
+  constexpr std::integral_constant<uint32_t, 4> kFour{};
   // rows [first, first + 4) of tile `tile`: loads (index clamped, like HistFetch) and counts (masked by row and by nvec)
   const uint32_t tileVecs = rows * kHistThreads;
   auto fetch = [&](auto streaming, uint32_t tile, uint32_t first, uint32_t nvec, u32x4 (&k)[4]) {
@@ -2038,18 +2138,16 @@ __global__ __launch_bounds__(kHistThreads) void histogram_msd_kernel(const uint3
       k[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(keys) + i) : reinterpret_cast<const u32x4*>(keys)[i];
     }
   };
-  auto tally = [&](uint32_t tile, uint32_t first, const u32x4 (&k)[4], uint32_t nvec) {
+  auto tally = [&](auto form, uint32_t tile, uint32_t first, const u32x4 (&k)[4], uint32_t nvec) {
 #pragma unroll
     for (uint32_t u = 0; u < 4; ++u) {
       if (first + u < rows && tile * tileVecs + (first + u) * kHistThreads + tid < nvec) {
-        count(k[u][0]);
-        count(k[u][1]);
-        count(k[u][2]);
-        count(k[u][3]);
+        const uint32_t four[4] = {k[u][0], k[u][1], k[u][2], k[u][3]};
+        count(form, kFour, four);
       }
     }
   };
-  // the tile's counts out, byte 3's share added up, the bins cleared
+  // the tile's counts out, added to the workgroup's bucket sizes, the bins cleared
   auto flush = [&](uint32_t tile) {
     LdsBarrier();
     for (uint32_t w = tid; w < D / 2; w += kHistThreads) {  // whole waves: D / 2 is a multiple of 64
@@ -2063,11 +2161,8 @@ __global__ __launch_bounds__(kHistThreads) void histogram_msd_kernel(const uint3
       }
 #pragma unroll
       for (uint32_t q = 0; q < TC / 2; ++q) mine[q] = u32x4{0u, 0u, 0u, 0u};
-      tileCounts[(size_t)tile * (D / 2) + w] = lo | (hi << 16);
-      uint32_t s = lo + hi;
-      s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0xB1, 0xf, 0xf, true);  // quad_perm:[1,0,3,2]
-      if (PER_BYTE == 4) s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x4E, 0xf, 0xf, true);  // quad_perm:[2,3,0,1]
-      if ((w & (PER_BYTE - 1)) == 0) byte3[w / PER_BYTE] += s;
+      a.tileCounts[(size_t)tile * (D / 2) + w] = lo | (hi << 16);
+      reinterpret_cast<u32x2*>(bucketSize)[w] += u32x2{lo, hi};
     }
     LdsBarrier();
   };
@@ -2075,24 +2170,75 @@ __global__ __launch_bounds__(kHistThreads) void histogram_msd_kernel(const uint3
   const uint32_t nvec = n >> 2;
   auto sweep = [&](auto streaming) {
     const uint32_t step = gridDim.x;
-    u32x4 a[4], b[4];
+    u32x4 a4[4], b4[4];
     uint32_t tile = blockIdx.x;
     const bool two = rows > 4;  // (uniform) tiles of more than four rows keep a second set of loads in flight
-    fetch(streaming, tile, 0, nvec, a);
-    if (two) fetch(streaming, tile, 4, nvec, b);
-    for (uint32_t i = tid; i < kByteWords + kMsdTopBinWords + 256u; i += kHistThreads) bins[i] = 0;
+    // the first loads fly while the counters are cleared and the prologue's word arrives
+    fetch(streaming, tile, 0, nvec, a4);
+    if (two) fetch(streaming, tile, 4, nvec, b4);
+    static_assert((kByteWords + kMsdTopBinWords + D) % 4u == 0, "cleared sixteen bytes at a time");
+    for (uint32_t i = tid; i < (kByteWords + kMsdTopBinWords + D) / 4u; i += kHistThreads)
+      reinterpret_cast<u32x4*>(bins)[i] = u32x4{0u, 0u, 0u, 0u};
     LdsBarrier();
-    for (; tile < tiles; tile += step) {
-      tally(tile, 0, a, nvec);
-      fetch(streaming, tile + step, 0, nvec, a);
-      if (two) {
-        tally(tile, 4, b, nvec);
-        fetch(streaming, tile + step, 4, nvec, b);
+    if (tid < 64u) {  // wave 0: what the sample says
+      const uint32_t differ = WaveOr(sampled) & WaveOr(~sampled);  // bits that are 1 in some sampled key and 0 in another
+      const uint32_t varying = differ != 0u ? 32u - (uint32_t)__clz((int)differ) : 0u;  // they all lie below this bit
+      // (never lower than bit 2: each of the bucket kernel's two passes then has a bit to rank by, and keys of twelve bits
+      // and fewer, for which that costs buckets, are rare at these sizes and quick in the four passes, two of which are trivial)
+      const uint32_t window = (varying > BITS + 2u ? varying : BITS + 2u) - BITS;
+      const uint32_t spread = varying > window ? varying - window : 0u;  // bits of the window that vary: <= BITS
+      uint32_t kind = kMsdModePlan;
+      if (n != 0u && varying == 0u) {
+        kind = kMsdModeIdentical;
+      } else if (spread < BITS && (uint64_t)n > ((uint64_t)a.cap << spread)) {
+        kind = kMsdModeDeclined;  // at most 2^spread buckets can hold anything
+      } else {
+        uint32_t* const bin = &top[__builtin_amdgcn_ubfe(sampled, window, BITS) * TC];
+        const uint32_t seen = atomicAdd(bin, 1u) + 1u;
+        // (the estimate as well: a short indirect count samples every key many times)
+        if (__ballot(seen >= kMsdSampleSkew && (uint64_t)seen * n / kMsdSampleKeys > a.cap) != 0ull) kind = kMsdModeDeclined;
+        *bin = 0u;  // (behind every lane's atomic: LDS operations of one wave are carried out in order)
       }
-      // the last one to three keys belong to the tile that holds key n - 1
-      if (tile == nvec / tileVecs && tid < (n & 3u)) count(keys[(nvec << 2) + tid]);
-      flush(tile);
+      if (tid == 0) {
+        verdict[0] = (window << kMsdShiftShift) | (kind << kMsdModeShift) | (kind == kMsdModeDeclined ? kMsdDeclineSample : 0u);
+        verdict[1] = sampled;
+      }
     }
+    LdsBarrier();
+    const uint32_t decided = verdict[0];
+    ref = verdict[1];
+    // for the launches behind this one (the fill in front has zeroed the word; keys outside the prefix are OR-ed into it too)
+    if (blockIdx.x == 0 && tid == 0) atomicOr(a.overflowWord, decided);
+    shift = (decided >> kMsdShiftShift) & kMsdShiftMask;
+    mode = (decided >> kMsdModeShift) & kMsdModeMask;
+    form = mode != kMsdModePlan ? (uint32_t)TABLES : (shift == 32u - BITS ? (uint32_t)TOP : (uint32_t)PREFIXED);
+    auto loop = [&](auto formTag) {
+      constexpr uint32_t FORM = decltype(formTag)::value;
+      if constexpr (FORM == PREFIXED) {  // (byte 3's own table: only this form counts in it)
+        for (uint32_t i = tid; i < VRDX_RADIX * C3; i += kHistThreads) byte3[i] = 0;
+        LdsBarrier();
+      }
+      for (; tile < tiles; tile += step) {
+        tally(formTag, tile, 0, a4, nvec);
+        fetch(streaming, tile + step, 0, nvec, a4);
+        if (two) {
+          tally(formTag, tile, 4, b4, nvec);
+          fetch(streaming, tile + step, 4, nvec, b4);
+        }
+        // the last one to three keys belong to the tile that holds key n - 1
+        if (tile == nvec / tileVecs && tid < (n & 3u)) {
+          const uint32_t one[1] = {keys[(nvec << 2) + tid]};
+          count(formTag, kOne, one);
+        }
+        if constexpr (FORM != TABLES) flush(tile);
+      }
+    };
+    if (form == TOP)
+      loop(std::integral_constant<uint32_t, TOP>{});
+    else if (form == PREFIXED)
+      loop(std::integral_constant<uint32_t, PREFIXED>{});
+    else
+      loop(std::integral_constant<uint32_t, TABLES>{});
   };
   const bool streamingInput = VRDX_HIST_NT == 2 || (VRDX_HIST_NT == 1 && n > kHistStreamingLoadsAbove);
   if (streamingInput) {
@@ -2101,63 +2247,96 @@ __global__ __launch_bounds__(kHistThreads) void histogram_msd_kernel(const uint3
   } else {
     sweep(std::false_type{});
   }
-  for (uint32_t i = blockIdx.x * kHistThreads + tid; i < statusVecs; i += gridDim.x * kHistThreads)
-    statusClear[i] = u32x4{0u, 0u, 0u, 0u};
+  if (form == PREFIXED && likeRef != 0u) atomicAdd(&byte3[(ref >> 24) * C3 + (tid & (C3 - 1))], likeRef);
   __syncthreads();
 
   if (tid < 3 * VRDX_RADIX) {
     uint32_t sum = 0;
 #pragma unroll
     for (uint32_t c = 0; c < COPIES; ++c) sum += bins[tid * COPIES + ((c + tid) & (COPIES - 1))];
-    if (sum != 0) atomicAdd(&globalHistogram[tid], sum);
+    if (sum != 0) atomicAdd(&a.histogramTable[tid], sum);
   } else {
-    const uint32_t sum = byte3[tid - 3 * VRDX_RADIX];
-    if (sum != 0) atomicAdd(&globalHistogram[tid], sum);
+    const uint32_t v = tid - 3 * VRDX_RADIX;  // a value of byte 3
+    uint32_t sum = 0;
+    if (form == TOP) {
+#pragma unroll
+      for (uint32_t q = 0; q < PER_BYTE; ++q) sum += bucketSize[v * PER_BYTE + q];
+    } else if (form == PREFIXED) {
+#pragma unroll
+      for (uint32_t c = 0; c < C3; ++c) sum += byte3[v * C3 + ((c + tid) & (C3 - 1))];
+    } else {
+#pragma unroll
+      for (uint32_t c = 0; c < COPIES; ++c) sum += top[v * COPIES + ((c + tid) & (COPIES - 1))];
+    }
+    if (sum != 0) atomicAdd(&a.histogramTable[tid], sum);
   }
+  // the bucket sizes, for the spine's bucket bases (under the top window they follow from byte 3's table, like in round 5)
+  if (form == PREFIXED) {
+    for (uint32_t d = tid; d < D; d += kHistThreads) {
+      const uint32_t mine = bucketSize[d];
+      if (mine != 0) atomicAdd(&a.bucketCount[d], mine);
+    }
+  }
+  // a key outside the prefix (PREFIXED), a key that is not the reference key (all sampled keys identical)
+  const uint32_t above = shift + BITS;  // < 32 in the PREFIXED form
+  const bool broken = form == PREFIXED ? (differs >> (above & 31u)) != 0u : (mode == kMsdModeIdentical && differs != 0u);
+  if (__ballot(broken) != 0ull && lane == 0) atomicOr(a.overflowWord, kMsdDeclinePrefix);
 }
 
 // ---- spine_msd_kernel -------------------------------------------------------------------------------
-// tileCounts[tile][w] (two 16-bit counts per word) -> exclusive prefixes over the tiles, in place; bucketBase / bucketCount.
+// tileCounts[tile][w] (two 16-bit counts per word) -> exclusive prefixes over the tiles, in place; bucketBase.
 // One workgroup per 16 words (32 buckets): thread (chunk, word) adds up its chunk of the rows -- 64 chunks, at most 32 rows
 // each, every load in flight at once, 64 bytes per row and workgroup -- the 64 chunk sums of a word are scanned by one
 // wave, and the thread walks its rows again from registers.  Totals are kept in 32 bits per digit: a bucket beyond 65535
 // must not go unnoticed because its half wrapped (the prefixes it leaves are garbage then, and nobody reads them).
-// The first bucket's base is the number of keys below it: a prefix of byte 3's histogram.
+// The first bucket's base is the number of keys in the buckets below it: the histogram kernel has added up every bucket's
+// size (bucketCount).  A plan that is already turned down (the prologue's prediction, a key outside the sampled prefix) or
+// has nothing to scatter (all keys identical) leaves only the fallback's status region to clear.
 template <uint32_t BITS>
 __global__ __launch_bounds__(1024) void spine_msd_kernel(MsdArgs a) {
   constexpr uint32_t D = 1u << BITS, ROW = D / 2;
   constexpr uint32_t WORDS = 16, CHUNKS = 64, MAXROWS = kMsdMaxTiles / CHUNKS;
-  __shared__ uint32_t sumLo[WORDS][CHUNKS], sumHi[WORDS][CHUNKS], total[2 * WORDS], below[4];
+  __shared__ uint32_t sumLo[WORDS][CHUNKS], sumHi[WORDS][CHUNKS], total[2 * WORDS], below[16];
   const uint32_t tid = threadIdx.x;
   const uint32_t j = tid & (WORDS - 1), c = tid / WORDS;
   const uint32_t w = blockIdx.x * WORDS + j;
   const uint32_t rows = (a.tiles + CHUNKS - 1) / CHUNKS;  // per chunk, <= MAXROWS (the host sees to it)
   const uint32_t r0 = c * rows;
   uint32_t* const column = a.tileCounts + w;
+  const uint32_t decided = *a.overflowWord;
 
   // status region 0 of the passes recorded behind the plan (nothing reads it before they start)
   {
     u32x4* const clear = reinterpret_cast<u32x4*>(a.statusClear);
     for (uint32_t i = blockIdx.x * 1024u + tid; i < a.statusVecs; i += gridDim.x * 1024u) clear[i] = u32x4{0u, 0u, 0u, 0u};
   }
-  // keys below this workgroup's first bucket
-  const uint32_t firstByte = (blockIdx.x * 2u * WORDS) >> (BITS - 8u);
-  uint32_t under = tid < 256u && tid < firstByte ? a.histogramTable[3u * VRDX_RADIX + tid] : 0u;
+  // keys in the buckets below this workgroup's first one: under the top window a prefix of byte 3's table, else of the bucket
+  // sizes the histogram kernel has added up
+  const uint32_t firstBucket = blockIdx.x * 2u * WORDS;
+  // (both asked for before `decided` has arrived: three loads per thread, not one more round trip per workgroup)
+  uint32_t underTop = tid < 256u && tid < (firstBucket >> (BITS - 8u)) ? a.histogramTable[3u * VRDX_RADIX + tid] : 0u;
+  uint32_t underSizes = 0;
+#pragma unroll
+  for (uint32_t d = tid; d < D; d += 1024u)
+    if (d < firstBucket) underSizes += a.bucketCount[d];
 
+  // (and so is the column: a plan that is turned down reads 2-4 MiB for nothing, 2 us; one that runs does not wait for the
+  // verdict first)
   uint32_t v[MAXROWS];
+#pragma unroll
+  for (uint32_t k = 0; k < MAXROWS; ++k) v[k] = (k < rows && r0 + k < a.tiles) ? column[(size_t)(r0 + k) * ROW] : 0u;
+  if ((decided & kMsdDeclineMask) != 0u || ((decided >> kMsdModeShift) & kMsdModeMask) != kMsdModePlan) return;  // nothing to scan
+  uint32_t under = ((decided >> kMsdShiftShift) & kMsdShiftMask) == 32u - BITS ? underTop : underSizes;
   uint32_t lo = 0, hi = 0;
 #pragma unroll
   for (uint32_t k = 0; k < MAXROWS; ++k) {
-    v[k] = (k < rows && r0 + k < a.tiles) ? column[(size_t)(r0 + k) * ROW] : 0u;
     lo += v[k] & 0xFFFFu;
     hi += v[k] >> 16;
   }
   sumLo[j][c] = lo;
   sumHi[j][c] = hi;
-  if (tid < 256u) {
-    under = WaveInclusiveScan(under);
-    if ((tid & 63u) == 63u) below[tid >> 6] = under;
-  }
+  under = WaveInclusiveScan(under);
+  if ((tid & 63u) == 63u) below[tid >> 6] = under;
   __syncthreads();
   {
     const uint32_t word = tid >> 6, chunk = tid & 63u;  // one wave per word
@@ -2183,10 +2362,12 @@ __global__ __launch_bounds__(1024) void spine_msd_kernel(MsdArgs a) {
     const uint32_t mine = tid < 2 * WORDS ? total[tid] : 0u;
     const uint32_t inclusive = WaveInclusiveScan(mine);
     if (tid < 2 * WORDS) {
-      const uint32_t d = blockIdx.x * 2u * WORDS + tid;
-      a.bucketBase[d] = below[0] + below[1] + below[2] + below[3] + inclusive - mine;
-      a.bucketCount[d] = mine;
-      if (mine > a.cap) atomicOr(a.overflowWord, 1u);
+      uint32_t base = inclusive - mine;
+#pragma unroll
+      for (uint32_t q = 0; q < 16; ++q) base += below[q];
+      a.bucketBase[firstBucket + tid] = base;
+      a.bucketCount[firstBucket + tid] = mine;  // (what the histogram kernel has added up below a prefix, the same number)
+      if (mine > a.cap) atomicOr(a.overflowWord, kMsdDeclineBucket);
     }
   }
 }
@@ -2220,7 +2401,7 @@ constexpr size_t ScatterMsdLdsWords() {
 template <uint32_t BITS, bool KV>
 __device__ __forceinline__ void ScatterMsdBody(const MsdArgs a) {
   constexpr int THREADS = 1024, KPT = 32, WAVES = THREADS / 64;
-  constexpr uint32_t TILE = kMsdTileKeys, D = 1u << BITS, SHIFT = 32u - BITS, MASK = D - 1u, ROW = D / 2u;
+  constexpr uint32_t TILE = kMsdTileKeys, D = 1u << BITS, ROW = D / 2u;
   static_assert(THREADS * KPT == TILE && ROW <= (uint32_t)THREADS && WAVES * ROW <= TILE, "geometry");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* const sorted = smem;               // TILE: keys (then values) regrouped by digit
@@ -2244,7 +2425,18 @@ __device__ __forceinline__ void ScatterMsdBody(const MsdArgs a) {
   const uint32_t tileStart = tile * frame;
   // Verdict first, loads second: a wave cannot end with loads in flight, so a launch that is turned down (a bucket beyond the
   // capacity: the four passes behind it run) would still read every key -- 22 us at 2^25 for nothing, measured.
-  if (*a.overflowWord != 0u) return;
+  const uint32_t decided = *a.overflowWord;
+  if ((decided & kMsdDeclineMask) != 0u) {
+    if (blockIdx.x == 0 && tid == 0 && a.declinedPlans != nullptr) atomicAdd(a.declinedPlans, 1u);  // (vrdxHipReadPlanCounters)
+    return;
+  }
+  // the window the prologue chose (uniform 32-bit keys: the top BITS bits); all keys identical: nothing to scatter, and
+  // the launches behind return on the verdict
+  const uint32_t SHIFT = (decided >> kMsdShiftShift) & kMsdShiftMask;
+  if (((decided >> kMsdModeShift) & kMsdModeMask) == kMsdModeIdentical) {
+    if (blockIdx.x == 0 && tid == 0) *a.planWord = kMsdVerdictSorted;
+    return;
+  }
   const uint32_t valid = tile < a.tiles && tileStart < n ? ((n - tileStart) < frame ? (n - tileStart) : frame) : 0u;
   const uint32_t tileEnd = tileStart + valid;
   const uint32_t loadBase = tileStart + wave * (slots * 64) + lane;
@@ -2256,14 +2448,14 @@ __device__ __forceinline__ void ScatterMsdBody(const MsdArgs a) {
     base0 = a.bucketBase[2 * tid];
     base1 = a.bucketBase[2 * tid + 1];
   }
-  if (blockIdx.x == 0 && tid == 0) *a.planWord = 3u;  // for the launches behind this one
+  if (blockIdx.x == 0 && tid == 0) *a.planWord = kMsdVerdictRuns | (SHIFT << kMsdShiftShift);  // for the launches behind this one
   if (valid == 0) return;
 
   uint32_t* const myRow = counters + wave * ROW;
 #pragma unroll
   for (uint32_t i = 0; i < ROW / 256u; ++i) reinterpret_cast<u32x4*>(myRow)[lane + 64 * i] = u32x4{0u, 0u, 0u, 0u};
   uint32_t rank[KPT / 2];  // ranks, then physical staging slots, two to a register
-  RankPacked16<KPT, DYN>(key, SHIFT, MASK, myRow, lane, rank, slots);
+  RankPacked16<KPT, DYN>(key, SHIFT, BITS, myRow, lane, rank, slots);
   ForgetDerivedValues<KPT>(key);
   LdsBarrier();
 
@@ -2279,7 +2471,7 @@ __device__ __forceinline__ void ScatterMsdBody(const MsdArgs a) {
     tileOffset[2 * tid + 1] = base1 + (prefixWord >> 16) - local1;
   }
   LdsBarrier();
-  PositionsPacked16<KPT, TILE, DYN>(key, SHIFT, MASK, myRow, rank, slots);
+  PositionsPacked16<KPT, TILE, DYN>(key, SHIFT, BITS, myRow, rank, slots);
   LdsBarrier();  // the counters are dead: the staging buffer takes their place
 #pragma unroll
   for (int i = 0; i < KPT; ++i) {
@@ -2318,8 +2510,8 @@ __device__ __forceinline__ void ScatterMsdBody(const MsdArgs a) {
         const uint32_t p = StagingSlot<TILE>(4u * (tid + j * THREADS));  // involution: the sorted position of the quad
         uint32_t d0, d3;
         if (keysPhase) {
-          d0 = w4[b][0] >> SHIFT;
-          d3 = w4[b][3] >> SHIFT;
+          d0 = __builtin_amdgcn_ubfe(w4[b][0], SHIFT, BITS);
+          d3 = __builtin_amdgcn_ubfe(w4[b][3], SHIFT, BITS);
           if constexpr (KV) quadDigits[j] = d0 | (d3 << 16);
         } else {
           d0 = quadDigits[KV ? j : 0] & 0xFFFFu;
@@ -2338,8 +2530,8 @@ __device__ __forceinline__ void ScatterMsdBody(const MsdArgs a) {
       if (boundaryQuad[s] == ~0u) continue;
       const u32x4 q = *reinterpret_cast<const u32x4*>(&sorted[StagingSlot<TILE>(boundaryQuad[s])]);
       if (keysPhase) {
-        boundaryDigits[s][0] = (q[0] >> SHIFT) | ((q[1] >> SHIFT) << 16);
-        boundaryDigits[s][1] = (q[2] >> SHIFT) | ((q[3] >> SHIFT) << 16);
+        boundaryDigits[s][0] = __builtin_amdgcn_ubfe(q[0], SHIFT, BITS) | (__builtin_amdgcn_ubfe(q[1], SHIFT, BITS) << 16);
+        boundaryDigits[s][1] = __builtin_amdgcn_ubfe(q[2], SHIFT, BITS) | (__builtin_amdgcn_ubfe(q[3], SHIFT, BITS) << 16);
       }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -2377,9 +2569,8 @@ __device__ __forceinline__ void BucketSort2Body(const MsdArgs a) {
   constexpr int WAVES = THREADS / 64;
   static_assert(THREADS == 1024 || THREADS == 512, "one or two words of a counter row per thread");
   constexpr uint32_t TILE = THREADS * KPT;
-  constexpr uint32_t W0 = 11u, W1 = 32u - BITS - W0;
   constexpr uint32_t ROW = 1024;  // 2048 packed counters per wave
-  static_assert(W1 >= 1 && W1 <= 11, "two passes of at most eleven bits");
+  static_assert(32u - BITS <= 22u, "two passes of at most eleven bits");
   static_assert(TILE <= 65536 && WAVES * ROW <= TILE && KPT % 4 == 0, "packed positions; the staging buffer covers the counters");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* const staged = smem;             // TILE
@@ -2389,7 +2580,16 @@ __device__ __forceinline__ void BucketSort2Body(const MsdArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  if (*a.planWord != 3u) return;  // the plan does not apply: the four passes are running
+  const uint32_t verdict = *a.planWord;
+  if ((verdict & kMsdVerdictMask) != kMsdVerdictRuns) return;  // the plan does not apply (the four passes are running), or nothing needs sorting
+  // The bits below the scatter's window, two to twenty-two (the window never lies lower than bit 2), in TWO passes of half
+  // the bits each: 11 | 11 under the top window of uniform keys.  (11 | 4 for the fifteen bits of dense 25-bit ids measured
+  // 146 us against 120: sixteen digits are eight counter words for 64 lanes, an eight-way conflict in every atomic of the
+  // second pass; 8 | 7 has none.  And always two passes, also where one would do: with a run-time number of passes the same
+  // loop ran 115 us instead of 108 for uniform keys.)
+  const uint32_t below = (verdict >> kMsdShiftShift) & kMsdShiftMask;
+  const uint32_t W0 = (below + 1u) / 2u, W1 = below / 2u;
+  constexpr uint32_t passes = 2u;
   const uint32_t myBase = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.bucketBase[blockIdx.x]);
   const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.bucketCount[blockIdx.x]);
   if (n == 0) return;
@@ -2428,38 +2628,46 @@ __device__ __forceinline__ void BucketSort2Body(const MsdArgs a) {
 
   uint32_t* const myRow = counters + wave * ROW;
 #pragma unroll 1
-  for (uint32_t pass = 0; pass < 2; ++pass) {
+  for (uint32_t pass = 0; pass < passes; ++pass) {
     const uint32_t shift = pass == 0 ? 0u : W0;
-    const uint32_t mask = pass == 0 ? (1u << W0) - 1u : (1u << W1) - 1u;
+    const uint32_t width = pass == 0 ? W0 : W1;
+    const uint32_t words = width > 1u ? 1u << (width - 1u) : 1u;  // of every wave's row that this pass counts in (two digits to a word)
 #pragma unroll
-    for (uint32_t i = 0; i < ROW / 256u; ++i) reinterpret_cast<u32x4*>(myRow)[lane + 64 * i] = u32x4{0u, 0u, 0u, 0u};
+    for (uint32_t i = 0; i < ROW / 256u; ++i)
+      if (256u * i < words) reinterpret_cast<u32x4*>(myRow)[lane + 64 * i] = u32x4{0u, 0u, 0u, 0u};
     uint32_t rank[KPT / 2];
-    RankPacked16<KPT, DYN>(key, shift, mask, myRow, lane, rank, slots);
+    RankPacked16<KPT, DYN>(key, shift, width, myRow, lane, rank, slots);
     ForgetDerivedValues<KPT>(key);
     LdsBarrier();
     uint32_t firstNow = first;  // (see SortInWorkgroup: keeps the read-back addresses out of registers across the passes)
     asm volatile("" : "+v"(firstNow));
     if constexpr (THREADS == 512) {  // two words of the row per thread
+      // (threads whose words no digit of this pass counts in only take part in the scan's barrier)
+      // (not in the key+value form: 121 of its 128 registers are taken, the test costs it seven and 12 bytes of scratch)
+      const bool mine = KV || 2u * (uint32_t)tid < words;
       u32x2 column[WAVES];
-      const u32x2 totals = ColumnPairRead<ROW, WAVES>(counters, tid, column);
+      const u32x2 totals = mine ? ColumnPairRead<ROW, WAVES>(counters, tid, column) : u32x2{0u, 0u};
       const uint32_t count0 = totals[0] & 0xFFFFu, count1 = totals[0] >> 16, count2 = totals[1] & 0xFFFFu;
       const uint32_t local0 = BlockExclusiveScanAll<THREADS>(count0 + count1 + count2 + (totals[1] >> 16), scanScratch + 16 * pass, tid);
       const uint32_t local2 = local0 + count0 + count1;
-      ColumnPairBasesFrom<ROW, WAVES>(counters, tid, u32x2{local0 | ((local0 + count0) << 16), local2 | ((local2 + count2) << 16)}, column);
+      if (mine)
+        ColumnPairBasesFrom<ROW, WAVES>(counters, tid, u32x2{local0 | ((local0 + count0) << 16), local2 | ((local2 + count2) << 16)}, column);
     } else if constexpr (!KV) {  // (key+value: the values are live as well; the column is read twice instead of kept)
+      const bool mine = (uint32_t)tid < words;
       uint32_t column[WAVES];
-      const uint32_t totals = ColumnRead<ROW, WAVES>(counters, tid, column);
+      const uint32_t totals = mine ? ColumnRead<ROW, WAVES>(counters, tid, column) : 0u;
       const uint32_t count0 = totals & 0xFFFFu;
       const uint32_t local0 = BlockExclusiveScanAll<THREADS>(count0 + (totals >> 16), scanScratch + 16 * pass, tid);
-      ColumnBasesFrom<ROW, WAVES>(counters, tid, local0 | ((local0 + count0) << 16), column);
+      if (mine) ColumnBasesFrom<ROW, WAVES>(counters, tid, local0 | ((local0 + count0) << 16), column);
     } else {
-      const uint32_t totals = ColumnTotals<ROW, WAVES>(counters, tid);
+      const bool mine = (uint32_t)tid < words;
+      const uint32_t totals = mine ? ColumnTotals<ROW, WAVES>(counters, tid) : 0u;
       const uint32_t count0 = totals & 0xFFFFu;
       const uint32_t local0 = BlockExclusiveScanAll<THREADS>(count0 + (totals >> 16), scanScratch + 16 * pass, tid);
-      ColumnBases<ROW, WAVES>(counters, tid, local0 | ((local0 + count0) << 16));
+      if (mine) ColumnBases<ROW, WAVES>(counters, tid, local0 | ((local0 + count0) << 16));
     }
     LdsBarrier();
-    PositionsPacked16<KPT, TILE, DYN>(key, shift, mask, myRow, rank, slots);
+    PositionsPacked16<KPT, TILE, DYN>(key, shift, width, myRow, rank, slots);
     LdsBarrier();  // the counters are dead: the staging buffer takes their place
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
@@ -2569,16 +2777,21 @@ constexpr size_t MsdFusedLdsWords(uint32_t bits, bool bucketLaunch) {
 
 template <uint32_t BITS, bool KV, bool DYN>
 __global__ __launch_bounds__(1024) void msd_scatter_or_pass0_kernel(MsdArgs m, OnesweepArgs p) {
-  if (*m.overflowWord == 0u)
+  if ((*m.overflowWord & kMsdDeclineMask) == 0u) {
     ScatterMsdBody<BITS, KV>(m);
-  else
+  } else {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && m.declinedPlans != nullptr) atomicAdd(m.declinedPlans, 1u);
+    // (the grid is the larger of the two roles': a workgroup beyond the pass's tiles has no ticket to take)
+    if (blockIdx.x > p.statusRows) return;
     FallbackPassBody<BITS, KV, DYN>(p);
+  }
 }
 template <uint32_t BITS, bool KV, bool DYN>
 __global__ __launch_bounds__(1024) void msd_buckets_or_pass1_kernel(MsdArgs m, OnesweepArgs p) {
-  if (*m.planWord == 3u)
+  const uint32_t verdict = *m.planWord & kMsdVerdictMask;
+  if (verdict == kMsdVerdictRuns)
     BucketSort2Body<BITS, (KV ? kMsdCapKeyValue : kMsdCapKeys) / 1024, KV>(m);
-  else
+  else if (verdict != kMsdVerdictSorted && blockIdx.x <= p.statusRows)
     FallbackPassBody<BITS, KV, DYN>(p);
 }
 
@@ -2668,7 +2881,7 @@ __global__ __launch_bounds__(1024) void lds_order_check_packed_kernel(uint32_t* 
     uint32_t key[16], got[8];
 #pragma unroll
     for (int i = 0; i < 16; ++i) key[i] = OrderCheckDigit11(tid, wave, round * 16 + i);
-    RankPacked16<16, false>(key, 0, 2047u, rowA, lane, got);
+    RankPacked16<16, false>(key, 0, 11u, rowA, lane, got);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const uint32_t d = key[i];
@@ -2990,8 +3203,8 @@ static hipError_t PrepareMsdBits() {
     const void* fn;
     size_t bytes;
   } kernels[] = {
-      {reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, BITS>), HistMsdLdsBytes(kHistCopies)},
-      {reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, BITS>), HistMsdLdsBytes(kHistCopiesLarge)},
+      {reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, BITS>), HistMsdLdsBytes(kHistCopies, BITS)},
+      {reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, BITS>), HistMsdLdsBytes(kHistCopiesLarge, BITS)},
       {reinterpret_cast<const void*>(&scatter_msd_kernel<BITS, false>), ScatterMsdLdsWords<BITS>() * 4},
       {reinterpret_cast<const void*>(&scatter_msd_kernel<BITS, true>), ScatterMsdLdsWords<BITS>() * 4},
       {reinterpret_cast<const void*>(&bucket_sort2_kernel<BITS, kMsdCapKeys / 1024, false>), BucketSort2LdsWords<kMsdCapKeys / 1024>() * 4},
@@ -3029,27 +3242,20 @@ hipError_t PrepareMsd() {
   return e;
 }
 
-hipError_t LaunchHistogramMsd(hipStream_t stream, uint32_t grid, const uint32_t* keys, uint32_t maxCount,
-                              const uint32_t* countPtr, uint32_t* globalHistogram, uint32_t* tickets, void* statusClear,
-                              uint32_t statusClearBytes, uint32_t* tileCounts, uint32_t tiles, uint32_t bits,
-                              uint32_t tileKeys) {
-  u32x4* const clear = reinterpret_cast<u32x4*>(statusClear);
-  const uint32_t vecs = statusClearBytes / 16u;
-  const bool many = maxCount >= kHistManyCopiesFrom;
+hipError_t LaunchHistogramMsd(hipStream_t stream, uint32_t grid, const MsdArgs& args) {
+  const bool many = args.maxCount >= kHistManyCopiesFrom;
   const void* kernel;
   // tiles of rows x 4096 keys (the scatter's even-split tiles); a tile of full capacity is eight rows
-  if (tileKeys == 0 || tileKeys % 4096u != 0 || tileKeys > kMsdTileKeys) return hipErrorInvalidValue;
-  const uint32_t rows = tileKeys / 4096u;
-  if (bits == 10)
+  if (args.tileKeys == 0 || args.tileKeys % 4096u != 0 || args.tileKeys > kMsdTileKeys) return hipErrorInvalidValue;
+  if (args.bits == 10)
     kernel = many ? reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, 10>)
                   : reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, 10>);
-  else if (bits == 11)
+  else if (args.bits == 11)
     kernel = many ? reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopiesLarge, 11>)
                   : reinterpret_cast<const void*>(&histogram_msd_kernel<kHistCopies, 11>);
   else
     return hipErrorInvalidValue;
-  return Launch(kernel, grid, kHistThreads, HistMsdLdsBytes(many ? kHistCopiesLarge : kHistCopies), stream, keys, maxCount,
-                countPtr, globalHistogram, tickets, clear, vecs, tileCounts, tiles, rows);
+  return Launch(kernel, grid, kHistThreads, HistMsdLdsBytes(many ? kHistCopiesLarge : kHistCopies, args.bits), stream, args);
 }
 
 hipError_t LaunchSpineMsd(hipStream_t stream, const MsdArgs& args) {
@@ -3109,8 +3315,14 @@ static hipError_t LaunchMsdFusedBits(hipStream_t stream, bool bucketLaunch, cons
                           : reinterpret_cast<const void*>(&msd_buckets_or_pass1_kernel<BITS, KV, false>))
                    : (dyn ? reinterpret_cast<const void*>(&msd_scatter_or_pass0_kernel<BITS, KV, true>)
                           : reinterpret_cast<const void*>(&msd_scatter_or_pass0_kernel<BITS, KV, false>));
+  // the larger of the two roles' grids, a multiple of 8 (the scatter derives its tile from the grid: eight chunks of tiles, one
+  // per XCD; a workgroup beyond its role's range returns)
   const uint32_t planGrid = bucketLaunch ? (1u << BITS) : 8u * ((m.tiles + 7u) / 8u);
-  return Launch(kernel, planGrid > passGrid ? planGrid : passGrid, 1024, MsdFusedLdsWords<KV>(BITS, bucketLaunch) * 4, stream, m, p);
+  const uint32_t grid = 8u * (((planGrid > passGrid ? planGrid : passGrid) + 7u) / 8u);
+  // the pass's run-time slot counts, checked like LaunchPairConfig / LaunchConfig do
+  if (dyn && (p.slots % 4 != 0 || p.slots > 32u || p.tailSlots % 4 != 0 || p.tailSlots == 0 || p.tailSlots > 32u))
+    return hipErrorInvalidValue;
+  return Launch(kernel, grid, 1024, MsdFusedLdsWords<KV>(BITS, bucketLaunch) * 4, stream, m, p);
 }
 
 hipError_t LaunchMsdFused(hipStream_t stream, bool bucketLaunch, bool keyValue, const MsdArgs& m, const OnesweepArgs& p,

@@ -97,9 +97,10 @@ struct StorageLayout {
   uint64_t ticketOffset;     // uint32[2], zeroed by the histogram kernel
   uint64_t failureOffset;    // uint32
   uint64_t histogramOffset;  // uint32[4][256]
-  uint64_t msdCountsOffset;  // MSD plan only: uint16[msdTiles][2^msdBits] per-tile counts / prefixes of the keys' top bits,
-  uint64_t msdCountsBytes;   //   on the first 128-byte line behind the table, in front of status region 0
-  uint64_t msdBucketOffset;  // MSD plan only: uint32[2][2^msdBits] bucket bases, then bucket sizes
+  uint64_t msdBucketOffset;  // MSD plan only, on the first 128-byte line behind the table: uint32 bucketCount[2^msdBits] (inside the
+                             //   prefix the fill zeroes: the histogram kernel adds into it), then bucketBase[2^msdBits]
+  uint64_t msdCountsOffset;  // MSD plan only: uint16[msdTiles][2^msdBits] per-tile counts / prefixes of the keys' window bits,
+  uint64_t msdCountsBytes;   //   behind them, in front of status region 0
   uint64_t statusOffset;     // uint32[2][rows + blockRows][256]: tile rows, then block rows, per region
   uint64_t statusRows;       // tile rows per region = max(tiles - 1, 0)
   uint64_t blockRows;        // block-sum rows per region (one per 32 tiles); 0 = classic look-back
@@ -128,16 +129,18 @@ static inline StorageLayout MakeLayout(uint32_t maxElementCount, uint32_t align,
   l.failureOffset = VRDX_OFF_FAILURE;
   l.histogramOffset = elementCountSize;
   const uint64_t tableEnd = l.histogramOffset + VRDX_PASSES * VRDX_RADIX * sizeof(uint32_t);
-  l.msdCountsOffset = tableEnd + ((0 - (storageAddress + tableEnd)) & 127u);  // the first 128-byte line behind the table
+  l.msdBucketOffset = tableEnd + ((0 - (storageAddress + tableEnd)) & 127u);  // the first 128-byte line behind the table
+  const uint64_t bucketWords = msdBits != 0 ? ((uint64_t)1 << msdBits) : 0;
+  l.msdCountsOffset = l.msdBucketOffset + 8 * bucketWords;                      // behind the two bucket tables
   l.msdCountsBytes = msdBits != 0 ? msdTiles * ((uint64_t)2 << msdBits) : 0;  // 16 bits per (tile, bucket)
-  l.msdBucketOffset = l.msdCountsOffset + l.msdCountsBytes;
-  l.statusOffset = l.msdBucketOffset + (msdBits != 0 ? ((uint64_t)8 << msdBits) : 0);  // (a multiple of 128 bytes like the rest)
+  l.statusOffset = l.msdCountsOffset + l.msdCountsBytes;  // (a multiple of 128 bytes like the rest)
   l.statusRows = tiles > 0 ? tiles - 1 : 0;
   l.blockRows = blockSums ? (tiles + VRDX_BLOCK_TILES - 1) / VRDX_BLOCK_TILES : 0;
   l.regionBytes = (l.statusRows + l.blockRows) * VRDX_RADIX * sizeof(uint32_t);
   // count + plan word + failure word + global histogram: what the histogram kernel's atomics and the passes' first
-  // reads need zeroed BEFORE that kernel starts; status region 0 is zeroed by the histogram kernel itself
-  l.clearBytes = tableEnd;
+  // reads need zeroed BEFORE that kernel starts (status region 0 is zeroed by the histogram kernel itself, or by the MSD
+  // plan's spine kernel); with the MSD plan also the bucket sizes, which its histogram kernel adds up with global atomics
+  l.clearBytes = msdBits != 0 ? l.msdBucketOffset + 4 * bucketWords : tableEnd;
   l.statusClearOffset = l.statusOffset;
   l.statusClearBytes = l.regionBytes;
   l.ticketOffset = l.statusOffset + 2 * l.regionBytes;
