@@ -4,8 +4,9 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--log2n 25]
 
 A "step" is one complete sort (whatever plan the library records for that size: at 2^25 the MSD plan --
-histogram, spine, scatter by the top ten bits, one in-LDS sort per bucket -- with the four onesweep passes
-behind it as the device-side fallback) of one batch of synthetic input:
+histogram, spine, scatter by a ten-bit window (for uniform keys the top ten bits), one in-LDS sort per bucket --
+with the four onesweep passes behind it as the device-side fallback; which of the two RAN in the timed region is
+read back from the device and stated, `roofline.plan_proof`) of one batch of synthetic input:
 N = 2^25 uniform-random u32 keys (BASELINE.json configs[1]); the key+value figure (configs[2]) is
 measured the same way and reported in the same JSON line under "key_value".  Inputs are resident
 in HBM before the timed region starts: every step sorts its own pre-generated array in place, so
@@ -15,8 +16,11 @@ bench/bench.cc:83-84).
 
 Behind the headline region (rank 0 of a 1-GPU run only) the line also carries the reference's size curve
 (bench/bench.cc:17-20,161-203: 1 warm-up + 10 timed runs on fresh data, median GPU time) at N = 2^18 ... 2^25
-for keys-only and key+value under "sweep", and one HBM-resident point at N = 2^27 (far past the 256 MiB
-Infinity Cache) under "hbm_resident".
+for keys-only and key+value under "sweep", one HBM-resident point at N = 2^27 (far past the 256 MiB
+Infinity Cache) under "hbm_resident", and BASELINE.json configs[3] -- the adversarial inputs at the headline size:
+all-equal, all-0xFFFFFFFF, descending, ascending, few-distinct(4), 24-bit keys; GItems/s, slowdown against uniform
+keys, the device's verdict, parity with values = iota -- under "adversarial".  The key+value half of the metric is
+`value_key_value` at the top level, next to `value`.
 
 Host memory is O(1) in --steps: the input streams are generated a few at a time on host threads, uploaded
 and freed; the pristine copies live on the device.
@@ -117,6 +121,7 @@ def timed_sorts(torch, dist, executor, pristine, n, steps, warmup, key_value, de
     for i in range(warmup):
         one(i)
     torch.cuda.synchronize()
+    counters_before = executor.plan_counters()   # (outside the timed region)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -128,6 +133,12 @@ def timed_sorts(torch, dist, executor, pristine, n, steps, warmup, key_value, de
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # What the DEVICE made of the plan the host recorded, for every sort of the timed region: the sorter counts the MSD plans
+    # it records and the device counts those it turns down (vrdxHipReadPlanCounters); the last sort's verdict word as well.
+    counters_after = executor.plan_counters()
+    proof = {"plan_taken_by_last_sort": executor.last_plan_taken(),
+             "msd_plans_recorded_in_timed_region": counters_after[0] - counters_before[0],
+             "msd_plans_declined_in_timed_region": counters_after[1] - counters_before[1]}
     # per-sort GPU time (median reported next to the headline): K more sorts on fresh data, outside
     # the timed region, each between two events on the sort's stream
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
@@ -152,7 +163,7 @@ def timed_sorts(torch, dist, executor, pristine, n, steps, warmup, key_value, de
         raise RuntimeError("output not sorted")
     del keys, values
     torch.cuda.empty_cache()
-    return elapsed, per_step_ms
+    return elapsed, per_step_ms, proof
 
 
 def stage_profile(torch, sorter, pristine, n, key_value, device, repeats=5):
@@ -231,10 +242,7 @@ def size_curve(torch, executor, sorter, pristine, device, log2_sizes, runs=11):
                     ms.append(start.elapsed_time(end))
             med = sorted(ms)[len(ms) // 2]
             plan = sorter.describe_plan(n, kv)
-            point["key_value" if kv else "keys"] = {
-                "gpu_ms": med, "gitems_per_s": n / (med * 1e-3) / 1e9, "plan": plan.name,
-                "bytes_per_item": int(plan.bytesPerElement),
-                "hbm_fraction": plan.bytesPerElement * n / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+            point["key_value" if kv else "keys"] = priced_point(plan, executor.last_plan_taken(), n, med)
         points.append(point)
     status = executor.finish()
     if status != 0:
@@ -268,13 +276,110 @@ def hbm_resident_point(torch, executor, sorter, pristine, device, lg=27, runs=6)
             del k, v
         med = sorted(ms)[len(ms) // 2]
         plan = sorter.describe_plan(n, kv)
-        out["key_value" if kv else "keys"] = {
-            "gpu_ms": med, "gitems_per_s": n / (med * 1e-3) / 1e9, "plan": plan.name,
-            "bytes_per_item": int(plan.bytesPerElement),
-            "hbm_fraction": plan.bytesPerElement * n / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        out["key_value" if kv else "keys"] = priced_point(plan, executor.last_plan_taken(), n, med)
     status = executor.finish()
     if status != 0:
         raise RuntimeError(f"sorter status 0x{status:08x} at N = 2^{lg}")
+    return out
+
+
+def bytes_moved_per_item(plan, taken):
+    """HBM bytes per element of the sort that RAN: the recorded plan's when the device took it (or when the plan is not
+    one the device decides about), the four passes' otherwise."""
+    decided_on_device = plan.name in ("msd", "hybrid-8")
+    return int(plan.bytesPerElement if (taken or not decided_on_device) else plan.fallbackBytesPerElement)
+
+
+def priced_point(plan, taken, n, ms):
+    per_item = bytes_moved_per_item(plan, taken)
+    return {"gpu_ms": ms, "gitems_per_s": n / (ms * 1e-3) / 1e9, "plan": plan.name,
+            "plan_taken": bool(taken) if plan.name in ("msd", "hybrid-8") else None,
+            "bytes_per_item": per_item, "hbm_fraction": per_item * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+
+
+ADVERSARIAL_PATTERNS = ("uniform", "all-equal", "all-0xFFFFFFFF", "descending", "ascending", "few-distinct(4)", "24-bit")
+
+
+def adversarial_block(torch, executor, sorter, pristine, n, device, runs=6):
+    """BASELINE.json configs[3] / BASELINE.md section 3: N = 2^25 adversarial keys (all-equal, all-0xFFFFFFFF -- the
+    padding sentinel --, descending N-1-i, ascending, few-distinct: four values; and 24-bit keys like the reference's
+    DataGenerator::Generate(n, 24), bench/data_generator.cc:15), keys-only and key+value with values = iota.  Protocol of
+    the size curve (bench/bench.cc:66-112: 1 warm-up + 5 timed runs, median GPU time between two events around the sort,
+    input restored on the device before every run).  Per pattern and mode: GItems/s, slowdown against uniform keys in
+    the same protocol, which sort ran (the device's verdict), and a proof of the permutation computed on the device:
+    keys ascending; key+value: keys_out == keys_in[values_out] and, inside every run of equal keys, values_out strictly
+    increasing -- together: THE stable sort (the oracle's predicate, bench/bench.cc:41-64, without the host)."""
+    import vulkan_radix_sort_amd as vrdx
+    iota = torch.arange(n, dtype=torch.int32, device=device)
+    u = pristine[0][0][:n]
+
+    def u32(x):
+        return x if x < (1 << 31) else x - (1 << 32)
+
+    def make(pattern):
+        if pattern == "uniform":
+            return u.clone()
+        if pattern == "all-equal":
+            return torch.full((n,), u32(0x12345678), dtype=torch.int32, device=device)
+        if pattern == "all-0xFFFFFFFF":
+            return torch.full((n,), -1, dtype=torch.int32, device=device)
+        if pattern == "descending":
+            return torch.arange(n - 1, -1, -1, dtype=torch.int32, device=device)
+        if pattern == "ascending":
+            return iota.clone()
+        if pattern == "few-distinct(4)":
+            four = torch.tensor([3, -1, 0x00010000, 0x7F000000], dtype=torch.int32, device=device)
+            return four[(u & 3).to(torch.int64)]
+        if pattern == "24-bit":
+            return ((u.to(torch.int64) & 0xFFFFFFFF) >> 8).to(torch.int32)
+        raise ValueError(pattern)
+
+    def unsigned(t):
+        return t.to(torch.int64) & 0xFFFFFFFF
+
+    out, base = [], {}
+    for pattern in ADVERSARIAL_PATTERNS:
+        src = make(pattern)
+        entry = {"keys_pattern": pattern}
+        for kv in (False, True):
+            ms = []
+            for r in range(runs):
+                k = src.clone()
+                v = iota.clone() if kv else None
+                start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                start.record()
+                executor.enqueue([(k, v)])
+                end.record()
+                torch.cuda.synchronize()
+                if r > 0:
+                    ms.append(start.elapsed_time(end))
+            med = sorted(ms)[len(ms) // 2]
+            plan = sorter.describe_plan(n, kv)
+            taken = executor.last_plan_taken()
+            identical = executor.last_plan_verdict() == vrdx.VERDICT_MSD_SORTED   # all keys identical: only the histogram read them
+            ku = unsigned(k)
+            ok = bool((ku[1:] >= ku[:-1]).all())
+            if kv:
+                vi = v.to(torch.int64)
+                ok = ok and bool((unsigned(src)[vi] == ku).all())
+                ok = ok and bool(((ku[1:] > ku[:-1]) | (vi[1:] > vi[:-1])).all())
+                del vi
+            del ku
+            base.setdefault(kv, med)
+            entry["key_value" if kv else "keys"] = {
+                "gpu_ms": med, "gitems_per_s": n / (med * 1e-3) / 1e9, "slowdown_vs_uniform": med / base[kv],
+                "plan_taken": bool(taken),
+                "ran": (plan.name + ": all keys identical, nothing moved") if identical else plan.name if taken else "four-passes",
+                "bytes_per_item": 4 if identical else bytes_moved_per_item(plan, taken), "parity": "ok" if ok else "MISMATCH"}
+            if not ok:
+                raise RuntimeError(f"adversarial input {pattern} ({'key+value' if kv else 'keys'}): wrong result")
+            del k, v
+        out.append(entry)
+        del src
+    status = executor.finish()
+    if status != 0:
+        raise RuntimeError(f"sorter status 0x{status:08x} in the adversarial block")
     return out
 
 
@@ -479,8 +584,8 @@ def main():
     to_first_region_s = time.perf_counter() - t_process   # start of main() -> inputs resident, first barrier next
     rss_inputs_mib = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0
     fresh = (pristine[0][total:], pristine[1][total:])   # never sorted in place
-    wall_keys, steps_keys = timed_sorts(torch, dist, executor, pristine, n, args.steps, args.warmup, False, device, distributed)
-    wall_kv, steps_kv = timed_sorts(torch, dist, executor, pristine, n, args.steps, args.warmup, True, device, distributed)
+    wall_keys, steps_keys, proof_keys = timed_sorts(torch, dist, executor, pristine, n, args.steps, args.warmup, False, device, distributed)
+    wall_kv, steps_kv, proof_kv = timed_sorts(torch, dist, executor, pristine, n, args.steps, args.warmup, True, device, distributed)
     stamped_keys = stage_profile(torch, sorter, fresh, n, False, device, repeats=5 if extras else 1)
     stamped_kv = stage_profile(torch, sorter, fresh, n, True, device, repeats=5 if extras else 1)
     # ONE definition of a launch duration on this line: the event interval around the kernel minus what a pair of event
@@ -549,6 +654,14 @@ def main():
 
     plan_keys, kernels_keys = kernels_of(stamped_keys, False)
     plan_kv, kernels_kv = kernels_of(stamped_kv, True)
+    # The whole sort is priced with the bytes of the plan that RAN in the timed region -- proven, not assumed: uniform keys
+    # must have taken the plan the host recorded in every one of its sorts (the device counts the plans it turns down).
+    for mode, plan, proof in (("keys-only", plan_keys, proof_keys), ("key+value", plan_kv, proof_kv)):
+        if plan.name in ("msd", "hybrid-8") and (not proof["plan_taken_by_last_sort"] or
+                                                  (plan.name == "msd" and proof["msd_plans_declined_in_timed_region"] != 0)):
+            raise RuntimeError(f"{mode}: the device turned the recorded {plan.name} plan down on uniform keys: {proof}")
+    bytes_keys = bytes_moved_per_item(plan_keys, proof_keys["plan_taken_by_last_sort"])
+    bytes_kv = bytes_moved_per_item(plan_kv, proof_kv["plan_taken_by_last_sort"])
 
     def dominant(kernels):
         movers = {k: v for k, v in kernels.items() if v["algorithmic_bytes_per_launch"] > 0 and k != "histogram"}
@@ -565,19 +678,20 @@ def main():
         "note": ("the dominant kernel is the one with the longest launch among those that move the data; 'bound' "
                  "prices it against HBM as the contract asks, 'limited_by' says what it actually waits for"),
         "limited_by": dom["limited_by"], "plan": plan_keys.name, "plan_bits": int(plan_keys.bits),
+        "plan_proof": proof_keys,
         "kernels": kernels_keys,
-        "whole_sort": {"algorithmic_bytes": float(plan_keys.bytesPerElement) * n,
-                       "bytes_per_item": int(plan_keys.bytesPerElement),
-                       "achieved": plan_keys.bytesPerElement * n / (med_keys_ms * 1e-3) / 1e9,
-                       "frac": plan_keys.bytesPerElement * n / (med_keys_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        "whole_sort": {"algorithmic_bytes": float(bytes_keys) * n,
+                       "bytes_per_item": bytes_keys,
+                       "achieved": bytes_keys * n / (med_keys_ms * 1e-3) / 1e9,
+                       "frac": bytes_keys * n / (med_keys_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                        "four_pass_equivalent_frac": KEYS_BYTES_PER_ITEM * n / (med_keys_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
         "key_value": {"kernel": dom_kv["kernel"], "avg_launch_ms": dom_kv["avg_launch_ms"],
                       "stamped_launch_ms": dom_kv["stamped_launch_ms"], "achieved": dom_kv["achieved"],
                       "frac": dom_kv["frac"], "traffic": dom_kv.get("traffic"), "limited_by": dom_kv["limited_by"],
-                      "plan": plan_kv.name, "plan_bits": int(plan_kv.bits), "kernels": kernels_kv,
-                      "whole_sort_bytes_per_item": int(plan_kv.bytesPerElement),
-                      "whole_sort_achieved": plan_kv.bytesPerElement * n / (med_kv_ms * 1e-3) / 1e9,
-                      "whole_sort_frac": plan_kv.bytesPerElement * n / (med_kv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                      "plan": plan_kv.name, "plan_bits": int(plan_kv.bits), "plan_proof": proof_kv, "kernels": kernels_kv,
+                      "whole_sort_bytes_per_item": bytes_kv,
+                      "whole_sort_achieved": bytes_kv * n / (med_kv_ms * 1e-3) / 1e9,
+                      "whole_sort_frac": bytes_kv * n / (med_kv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                       "four_pass_equivalent_frac": KV_BYTES_PER_ITEM * n / (med_kv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
     }
     if "traffic" in dom:
@@ -601,6 +715,8 @@ def main():
                    "parallelism": "independent arrays, one per GPU, no data-path collective" if distributed else "single GPU",
                    "tile": version, "plan": plan_keys.name, "ranks": [{"rank": r.rank, "status": r.status} for r in records]},
         "median_gpu_ms_per_sort": med_keys_ms, "median_gitems_per_s": n / (med_keys_ms * 1e-3) / 1e9,
+        # the key+value half of the metric (configs[2]), top level so that it is read with the keys-only `value`
+        "value_key_value": value_kv, "ms_per_step_key_value": wall_kv / args.steps * 1e3,
         "key_value": {"value": value_kv, "unit": "GItems/s", "ms_per_step": wall_kv / args.steps * 1e3,
                       "median_gpu_ms_per_sort": med_kv_ms, "median_gitems_per_s": n / (med_kv_ms * 1e-3) / 1e9},
         "targets": {"cub_onesweep_rtx5080_keys": 22.36, "cub_onesweep_rtx5080_key_value": 11.67,
@@ -610,6 +726,14 @@ def main():
                   "streams": len(pristine[0]), "host_streams_in_flight": GENERATOR_THREADS,
                   "rss_mib_runtime_up": rss_runtime_mib, "rss_mib_inputs_resident": rss_inputs_mib},
     }
+    if extras and args.log2n >= 23:
+        # BASELINE.json configs[3]: the adversarial inputs at the headline size, in every run of this command
+        t_adv = time.perf_counter()
+        result["adversarial"] = adversarial_block(torch, executor, sorter, fresh, n, device)
+        result["adversarial_protocol"] = ("bench/bench.cc:66-112 as in `sweep`: 1 warm-up + 5 timed sorts per pattern and mode, "
+                                          "median GPU time; values = iota; slowdown against the 'uniform' row; plan_taken = the "
+                                          "device's verdict (vrdxHipReadPlanVerdict); parity proven on the device; measured on "
+                                          + box + " in %.1f s" % (time.perf_counter() - t_adv))
     if extras and not args.no_sweep:
         t_curve = time.perf_counter()
         result["sweep"] = size_curve(torch, executor, sorter, fresh, device, list(range(18, args.log2n + 1)))

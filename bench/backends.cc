@@ -188,6 +188,16 @@ class HipBenchmark : public BenchmarkBase {
     }
     r.total_time = static_cast<uint64_t>(double(ms) * 1e6);
     r.cpu_time = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(cpuEnd - cpuStart).count());
+    {
+      // what the timed sort moved: the plan the host recorded if the device took it, the four passes if it did not
+      VrdxHipPlanInfo plan;
+      vrdxHipDescribePlan(sorter_, n, keyValue ? 1 : 0, &plan);
+      const uint32_t verdict = vrdxHipReadPlanVerdict((VkCommandBuffer)stream_, (VkBuffer)storage_, 0);
+      const bool decidedOnDevice = plan.plan == VRDX_HIP_PLAN_MSD || plan.plan == VRDX_HIP_PLAN_HYBRID8;
+      const bool taken = verdict == VRDX_HIP_VERDICT_MSD_RUNS || verdict == VRDX_HIP_VERDICT_MSD_SORTED ||
+                         verdict == VRDX_HIP_VERDICT_HYBRID8_RUNS;
+      r.bytes_per_element = decidedOnDevice && !taken ? plan.fallbackBytesPerElement : plan.bytesPerElement;
+    }
 
     // stage split (bench/vulkan_benchmark.cc:330-337) from one more sort of the now sorted data
     // with the 15-slot timestamp contract active; not part of total_time

@@ -20,6 +20,9 @@ class BenchmarkBase {
     uint64_t upsweep_ns = 0;    // ns, summed over the 4 passes (ours: the fused histogram)
     uint64_t spine_ns = 0;      // ns (ours: 0, the scan is the look-back inside downsweep)
     uint64_t downsweep_ns = 0;  // ns, summed over the 4 passes
+    // HBM bytes per element of the sort that ran (hip: the recorded plan's, vrdxHipDescribePlan, when the device took it --
+    // vrdxHipReadPlanVerdict --, the four passes' otherwise); 0 = not known: priced as four passes
+    uint32_t bytes_per_element = 0;
   };
   virtual ~BenchmarkBase() = default;
   virtual std::string LibraryVersion() const { return ""; }

@@ -53,7 +53,10 @@ class Series {
   void Add(const BenchmarkBase::Results& r) {
     const uint64_t sample[kColumns] = {r.total_time, r.cpu_time, r.upsweep_ns, r.spine_ns, r.downsweep_ns};
     for (int c = 0; c < kColumns; ++c) ns_[c].push_back(sample[c]);
+    if (r.bytes_per_element != 0) bytesPerElement_ = r.bytes_per_element;
   }
+  // of the last run that said so (the plan is a function of N and the mode; the device's verdict of the data); 0: unknown
+  uint32_t BytesPerElement() const { return bytesPerElement_; }
   // upper median, like the reference's (element size/2 of the sorted series)
   double MedianMs(Column c) const {
     std::vector<uint64_t> sorted(ns_[c]);
@@ -64,6 +67,7 @@ class Series {
 
  private:
   std::vector<uint64_t> ns_[kColumns];
+  uint32_t bytesPerElement_ = 0;
 };
 
 struct Line {
@@ -75,9 +79,14 @@ struct Line {
     const double ms = Ms(c);
     return ms > 0.0 ? static_cast<double>(n) / (ms * 1e6) : 0.0;
   }
-  double AlgorithmicGBps() const {  // 36 B/key, 68 B/pair
+  // HBM bytes the sort moved over its device time: the bytes of the plan that RAN where the backend says which
+  // (hip: 20 B/key and 36 B/pair for the two-trip plans, vrdxHipDescribePlan + vrdxHipReadPlanVerdict), else the four
+  // passes' of SURVEY.md section 8(d): 36 B/key, 68 B/pair.  (Column names as tools/plot.py expects them,
+  // /root/reference/tools/plot.py:25-50.)
+  double AlgorithmicGBps() const {
     const double ms = Ms(Series::kDevice);
-    return ms > 0.0 ? (std::strcmp(sort, "keys") == 0 ? 36.0 : 68.0) * n / (ms * 1e6) : 0.0;
+    const double bytes = series.BytesPerElement() != 0 ? series.BytesPerElement() : (std::strcmp(sort, "keys") == 0 ? 36.0 : 68.0);
+    return ms > 0.0 ? bytes * n / (ms * 1e6) : 0.0;
   }
 };
 

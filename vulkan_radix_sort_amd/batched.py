@@ -126,6 +126,27 @@ class HipShardExecutor:
         self.enqueue(arrays)
         return self.finish()
 
+    def last_plan_taken(self) -> bool:
+        """Whether the two-trip plan recorded for the LAST sort enqueued (``Sorter.describe_plan``: hybrid-8 or msd) ran on
+        the device, or the four passes behind it did (``vrdxHipReadPlanVerdict``; waits for that sort)."""
+        if self._storage is None:
+            return False
+        stream = (self._last or self.torch.cuda.current_stream(self.device)).cuda_stream
+        return self.sorter.plan_taken(stream, self._storage.data_ptr(), 0)
+
+    def last_plan_verdict(self) -> int:
+        """``vrdxHipReadPlanVerdict`` for the last sort enqueued (``VERDICT_*``; waits for that sort)."""
+        if self._storage is None:
+            return 0
+        stream = (self._last or self.torch.cuda.current_stream(self.device)).cuda_stream
+        return self.sorter.read_plan_verdict(stream, self._storage.data_ptr(), 0)
+
+    def plan_counters(self):
+        """(sorts recorded with the MSD plan in front, how many of them the device turned down) since the executor was
+        made (``vrdxHipReadPlanCounters``; waits for the sorts in flight)."""
+        stream = (self._last or self.torch.cuda.current_stream(self.device)).cuda_stream
+        return self.sorter.read_plan_counters(stream)
+
     def close(self):
         self.sorter.destroy()
 
