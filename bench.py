@@ -60,6 +60,7 @@ def parse_args():
     p.add_argument("--log2n", type=int, default=25)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-sweep", action="store_true")   # only the headline region and the roofline
+    p.add_argument("--no-adversarial", action="store_true")   # (with --no-sweep: every launch a profiler sees is a headline sort)
     return p.parse_args()
 
 
@@ -726,7 +727,7 @@ def main():
                   "streams": len(pristine[0]), "host_streams_in_flight": GENERATOR_THREADS,
                   "rss_mib_runtime_up": rss_runtime_mib, "rss_mib_inputs_resident": rss_inputs_mib},
     }
-    if extras and args.log2n >= 23:
+    if extras and args.log2n >= 23 and not args.no_adversarial:
         # BASELINE.json configs[3]: the adversarial inputs at the headline size, in every run of this command
         t_adv = time.perf_counter()
         result["adversarial"] = adversarial_block(torch, executor, sorter, fresh, n, device)

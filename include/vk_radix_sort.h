@@ -142,11 +142,11 @@ void vrdxGetSorterKeyValueStorageRequirements(VrdxSorter sorter, uint32_t maxEle
  *                 with the previous pass's "downsweep" slot for i > 0)
  *   HYBRID8       the same, plus [4,5] = one workgroup per bucket (pass 1's "upsweep"); passes 1-3 return at once
  *                 when the device takes the plan
- *   MSD           [0,1] prologue (clear + window choice); [1,2] histogram; [2,3] spine; [3,4] scatter by the
+ *   MSD           [1,2] histogram (it also chooses the window); [2,3] spine; [3,4] scatter by the
  *                 window bits; [4,5] one workgroup per bucket; the passes that are launches of their own follow
- *                 in their "downsweep" slots ([6,7] pass 1, [9,10] pass 2, [12,13] pass 3) and return at once
- *                 when the device takes the plan (keys-only: passes 0 and 1 are second roles of the scatter and
- *                 bucket launches and have no slot)
+ *                 and return at once when the device takes the plan: [9,10] pass 2, [12,13] pass 3, and for key+value
+ *                 sorts [6,7] passes 0 and 1 together (keys-only: passes 0 and 1 are second roles of the scatter and
+ *                 bucket launches -- when the device turns the plan down, [3,4] and [4,5] ARE passes 0 and 1)
  *   ONE_WORKGROUP [13,14] the one kernel
  */
 void vrdxCmdSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t elementCount,

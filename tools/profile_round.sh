@@ -10,9 +10,10 @@ cd $ROOT
 export TMPDIR=/tmp
 # 1. bench line
 timeout 900 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
-# 2. kernel trace + stats of the same command (without the CPU baseline and without the size curve: every launch the
-#    profiler then sees is a sort of the headline size, so its per-kernel averages are comparable with the line's)
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kernel_stats -o stats -- python3 bench.py --no-cpu-baseline --no-sweep > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err
+# 2. kernel trace + stats of the same command (without the CPU baseline, the size curve and the adversarial inputs: every
+#    launch the profiler then sees is a sort of uniform keys of the headline size, so its per-kernel averages are comparable
+#    with the line's)
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kernel_stats -o stats -- python3 bench.py --no-cpu-baseline --no-sweep --no-adversarial > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err
 S=$(find $OUT/kernel_stats -name '*kernel_stats.csv' | head -1)
 cp "$S" $OUT/rocprofv3_kernel_stats.csv 2>/dev/null
 python3 tools/kernel_stats.py "$S" --json $OUT/kernel_stats.json > $OUT/kernel_stats.txt 2>&1

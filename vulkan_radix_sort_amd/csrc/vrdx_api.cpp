@@ -492,7 +492,7 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
   const uint32_t statusRows = (uint32_t)layout.statusRows;
 
   // the MSD plan's arguments: spine (prefixes over the tiles, bucket table, verdict), scatter by the window bits, one
-  // workgroup per bucket; the prologue and the histogram kernel take the same structure
+  // workgroup per bucket; the histogram kernel takes the same structure
   vrdx::MsdArgs m;
   std::memset(&m, 0, sizeof(m));
   if (msdBits != 0) {

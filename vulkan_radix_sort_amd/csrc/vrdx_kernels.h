@@ -151,7 +151,7 @@ constexpr uint32_t kMsdHalfCap = 18432;    // buckets of the half-size bucket ke
 // What the histogram kernel decides travels in the OVERFLOW WORD itself (VRDX_OFF_MSD_OVERFLOW), so that every launch behind it learns
 // "is the plan turned down, where is the window, what kind of input is it" from the one word it reads anyway -- a second
 // word would be a second dependent memory round trip in front of the first key load of every workgroup:
-//   bits 0-7   non-zero = the plan is turned down (kMsdDecline*: by the spine, the histogram kernel, the prologue)
+//   bits 0-7   non-zero = the plan is turned down (kMsdDecline*: by the spine or by the histogram kernel)
 //   bits 8-13  shift: the scatter ranks by (key >> shift) & (2^bits - 1); the bucket kernel sorts the `shift` bits below
 //   bits 16-17 MsdMode
 // The scatter passes the shift on in the verdict word (kMsdVerdict* | shift << 8) for the same reason.
@@ -188,7 +188,7 @@ struct MsdArgs {
   uint32_t* histogramTable;    // uint[4][256]
   uint32_t* tileCounts;        // [tiles][2^bits / 2] words = pairs of 16-bit numbers: counts, then prefixes over the tiles
   uint32_t* bucketBase;        // [2^bits]
-  uint32_t* bucketCount;       // [2^bits]: zeroed by the prologue, added up by the histogram kernel
+  uint32_t* bucketCount;       // [2^bits]: zeroed by the fill in front of the sort; added up by the histogram kernel (windows below a prefix) or by the spine
   uint32_t* overflowWord;      // VRDX_OFF_MSD_OVERFLOW in the storage: non-zero = the plan is turned down
   uint32_t* planWord;          // VRDX_OFF_PLAN: the scatter writes kMsdVerdictRuns / kMsdVerdictSorted (the passes then return)
   uint32_t bits;               // 10 | 11

@@ -23,7 +23,8 @@
 //   * small_sort_kernel / bucket_sort_kernel -- sorts of up to 16384 elements in one workgroup; the hybrid plan of
 //     mid-size sorts (one scatter by the highest varying byte, then every bucket in LDS).
 //   * histogram_msd_kernel / spine_msd_kernel / scatter_msd_kernel / bucket_sort2[_half]_kernel -- the MSD plan of sorts
-//     of 8.14 M ... 67 M elements: one chain-free scatter by the top 10-11 bits, then every bucket in LDS in two passes.
+//     of 8.14 M ... 67 M elements: one chain-free scatter by a window of 10-11 bits (the top ones for uniform keys, chosen on
+//     the device below the keys' common prefix otherwise), then every bucket in LDS in two passes.
 //   Tile ids are handed out by an atomic ticket in ARRIVAL order, so a look-back only ever waits
 //   on a tile that is already running; every spin is bounded (failure word, never a hang).
 #include <hip/hip_runtime.h>
@@ -2015,7 +2016,7 @@ __device__ __forceinline__ uint32_t WaveOr(uint32_t v) {
 
 // ---- histogram_msd_kernel ---------------------------------------------------------------------------
 // histogram_kernel (same pipeline: two groups of four 16-byte loads per lane in flight, all workgroups inside one window of
-// the input) with a fifth table: the keys' WINDOW bits (MsdWindow: (key >> shift) & (2^BITS - 1), the prologue's choice),
+// the input) with a fifth table: the keys' WINDOW bits ((key >> shift) & (2^BITS - 1), the window chosen above),
 // counted PER TILE of up to 32768 keys in 2^BITS bins x TC replicas of 32 KiB in all; after each tile the 2^BITS counts go
 // out as 16-bit numbers (a tile holds at most 32768 keys: 0x8000 fits), are added to the workgroup's bucket sizes and
 // cleared.  A wave whose 64 keys share their window bits would serialise 16-way on TC replicas: one lane adds 64 instead.
@@ -2025,8 +2026,8 @@ __device__ __forceinline__ uint32_t WaveOr(uint32_t v) {
 //   PREFIXED  the window lies below a common prefix: byte 3 has a table of its own (the fallback needs all four if a key
 //             breaks the prefix), and every key is XOR-ed against the reference key -- a difference above the window raises
 //             the overflow word;
-//   TABLES    the prologue has turned the plan down, or found every sampled key identical: the four byte tables only,
-//             like histogram_kernel; in the second case any key that differs from the reference raises the overflow word.
+//   TABLES    the sample has turned the plan down, or every sampled key is identical: the four byte tables only, like
+//             histogram_kernel; in the second case any key that differs from the reference raises the overflow word.
 constexpr uint32_t kMsdTopBinWords = 8192;  // 32 KiB: 1024 bins x 8 replicas | 2048 x 4
 
 constexpr uint32_t HistMsdByte3Copies(uint32_t copies) { return copies < 16u ? copies : 16u; }
@@ -2173,7 +2174,7 @@ __global__ __launch_bounds__(kHistThreads) void histogram_msd_kernel(MsdArgs a) 
     u32x4 a4[4], b4[4];
     uint32_t tile = blockIdx.x;
     const bool two = rows > 4;  // (uniform) tiles of more than four rows keep a second set of loads in flight
-    // the first loads fly while the counters are cleared and the prologue's word arrives
+    // the first loads (and wave 0's sample in front of them) fly while the counters are cleared
     fetch(streaming, tile, 0, nvec, a4);
     if (two) fetch(streaming, tile, 4, nvec, b4);
     static_assert((kByteWords + kMsdTopBinWords + D) % 4u == 0, "cleared sixteen bytes at a time");
@@ -2290,7 +2291,7 @@ __global__ __launch_bounds__(kHistThreads) void histogram_msd_kernel(MsdArgs a) 
 // wave, and the thread walks its rows again from registers.  Totals are kept in 32 bits per digit: a bucket beyond 65535
 // must not go unnoticed because its half wrapped (the prefixes it leaves are garbage then, and nobody reads them).
 // The first bucket's base is the number of keys in the buckets below it: the histogram kernel has added up every bucket's
-// size (bucketCount).  A plan that is already turned down (the prologue's prediction, a key outside the sampled prefix) or
+// size (bucketCount).  A plan that is already turned down (the sample's prediction, a key outside the sampled prefix) or
 // has nothing to scatter (all keys identical) leaves only the fallback's status region to clear.
 template <uint32_t BITS>
 __global__ __launch_bounds__(1024) void spine_msd_kernel(MsdArgs a) {
@@ -2430,7 +2431,7 @@ __device__ __forceinline__ void ScatterMsdBody(const MsdArgs a) {
     if (blockIdx.x == 0 && tid == 0 && a.declinedPlans != nullptr) atomicAdd(a.declinedPlans, 1u);  // (vrdxHipReadPlanCounters)
     return;
   }
-  // the window the prologue chose (uniform 32-bit keys: the top BITS bits); all keys identical: nothing to scatter, and
+  // the window the histogram kernel chose (uniform 32-bit keys: the top BITS bits); all keys identical: nothing to scatter, and
   // the launches behind return on the verdict
   const uint32_t SHIFT = (decided >> kMsdShiftShift) & kMsdShiftMask;
   if (((decided >> kMsdModeShift) & kMsdModeMask) == kMsdModeIdentical) {

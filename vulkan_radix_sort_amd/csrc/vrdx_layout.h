@@ -9,11 +9,14 @@
 //
 //   byte offset from S (A = 16)                     reference use              our use
 //   [0, 4)                                          element count              element count (indirect: copied)
-//   [4, 8)                                          (padding)                  hybrid plan's verdict (VRDX_OFF_PLAN)
+//   [4, 8)                                          (padding)                  the plan's verdict (VRDX_OFF_PLAN)
+//   [8, 12)                                         (padding)                  MSD plan: window, kind of input, "turned down" (VRDX_OFF_MSD_OVERFLOW)
 //   [12, 16)                                        (padding)                  failure word
 //   [A, A+4096)                                     globalHistogram[4][256]    the same table (raw counts)
-//   statusOffset = first 128-byte boundary          partitionHistogram[P][256] tile status[2][rows][256]
-//                  at or behind A+4096
+//   first 128-byte boundary at or behind A+4096     partitionHistogram[P][256] MSD plan only: uint32 bucketCount[2^bits] (zeroed with
+//                                                                              the prefix), bucketBase[2^bits], then uint16
+//                                                                              tileCounts[msdTiles][2^bits]
+//   statusOffset = behind them                                                 tile status[2][rows][256]
 //   ticketOffset = end of the status regions                                   tile tickets[2], a 128-byte line of their own
 //   inoutOffset  = ticketOffset + 128               keys scratch uint[N]       keys scratch uint[N]     (128-byte aligned)
 //   valuesOffset = inoutOffset + Align(4 N, 128)    values scratch uint[N]     values scratch uint[N]   (128-byte aligned)
@@ -66,11 +69,15 @@
 /* offsets inside the first 16 bytes */
 #define VRDX_OFF_COUNT 0u
 #define VRDX_OFF_FAILURE 12u
-// word 1 of the storage (zeroed with the rest of the prefix before every sort): the hybrid plan's verdict, written by
-// launch 0 -- 1 = the plan applies (launches 1-3 return at once), 2 = the four passes run (the bucket launch returns)
+// word 1 of the storage (zeroed with the rest of the prefix before every sort): the plan's verdict (vrdxHipReadPlanVerdict).
+// Eight-bit hybrid plan, written by launch 0: 1 = the plan applies (launches 1-3 return at once), 2 = the four passes run (the
+// bucket launch returns).  MSD plan, written by its scatter launch: 3 = the plan runs (| the window's shift << 8), 4 = all
+// keys identical, nothing to do; the passes behind return on either.
 #define VRDX_OFF_PLAN 4u
-// word 2 (zeroed likewise): the MSD plan's spine raises it when a bucket exceeds the capacity -- the plan's scatter and
-// bucket launches then return and the four passes run (vrdx_kernels.hip, "MSD plan")
+// word 2 (zeroed likewise): the MSD plan's word -- its low byte is raised by the spine when a bucket exceeds the capacity, by
+// the histogram kernel for a key outside the sampled prefix or a sample that rules the plan out: the plan's scatter and
+// bucket launches then return and the four passes run; above it the window's shift and the kind of input
+// (vrdx_kernels.h, kMsdDecline* / kMsdShiftShift / kMsdModeShift)
 #define VRDX_OFF_MSD_OVERFLOW 8u
 
 #ifdef __cplusplus
