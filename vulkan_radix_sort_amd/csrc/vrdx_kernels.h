@@ -206,6 +206,8 @@ hipError_t PrepareMsd();
 hipError_t LaunchHistogramMsd(hipStream_t stream, uint32_t grid, const MsdArgs& args);
 hipError_t LaunchSpineMsd(hipStream_t stream, const MsdArgs& args);
 hipError_t LaunchScatterMsd(hipStream_t stream, bool keyValue, const MsdArgs& args);
+// (round 6, experiment: two tiles per workgroup, keys-only, ten bits -- runs of twice the length)
+hipError_t LaunchScatterMsdPair(hipStream_t stream, const MsdArgs& args);
 hipError_t LaunchBucketSort2(hipStream_t stream, bool keyValue, const MsdArgs& args);
 // The scatter (bucketLaunch = false) or bucket (true) launch of the plan with pass 0 / pass 1 of its fallback as a second
 // role, chosen on the device by the plan's verdict: saves two of the four returning launches.  `pass` = the arguments and

@@ -1959,7 +1959,7 @@ __device__ __forceinline__ void ColumnPairBasesFrom(uint32_t* counters, uint32_t
 
 // ranks -> physical staging slots, in place: slot = StagingSlot(row[digit] + rank).  Reads only; the staging buffer may
 // alias the counters once every wave has been through here (the caller's barrier).
-template <int KPT, uint32_t STAGE, bool DYN>
+template <int KPT, uint32_t STAGE, bool DYN, bool RAW = false>  // RAW: the position itself, not its swizzled staging slot
 __device__ __forceinline__ void PositionsPacked16(const uint32_t (&key)[KPT], uint32_t shift, uint32_t width,
                                                   const uint32_t* myRow, uint32_t (&rankThenSlot)[KPT / 2],
                                                   uint32_t slots = KPT) {
@@ -1974,7 +1974,8 @@ __device__ __forceinline__ void PositionsPacked16(const uint32_t (&key)[KPT], ui
     for (int c = 0; c < CHUNK; ++c) {
       const int i = base + c;
       const uint32_t r = (rankThenSlot[i / 2] >> (16 * (i % 2))) & 0xFFFFu;
-      w[c] = StagingSlot<STAGE>(((w[c] >> DigitHalf(key[i], shift)) & 0xFFFFu) + r);
+      const uint32_t position = ((w[c] >> DigitHalf(key[i], shift)) & 0xFFFFu) + r;
+      w[c] = RAW ? position : StagingSlot<STAGE>(position);
     }
 #pragma unroll
     for (int c = 1; c < CHUNK; c += 2) {
@@ -2552,6 +2553,155 @@ __device__ __forceinline__ void ScatterMsdBody(const MsdArgs a) {
     LdsBarrier();
     scatterQuads(a.valuesScratch, false);
   }
+}
+
+// ---- scatter_msd_pair_kernel (round 6, experiment: VRDX_MSD_PAIR=1) --------------------------------------
+// TWO consecutive tiles A, B per workgroup, keys-only.  What the scatter pays for is its write pattern: a tile of 32768 keys
+// over 1024 buckets writes runs of 128 bytes at 4-byte alignment, 1.45 x the bytes (profiles/r05_pmc_traffic.json).  In memory a
+// tile's run of bucket d is followed by the NEXT tile's run of bucket d (prefix[B][d] = prefix[A][d] + count[A][d]), so a
+// workgroup that holds both tiles writes ONE run of twice the length: both tiles' keys in registers (the two-sub-tile pass
+// kernel's trick), ranked with a counter row per (sub-tile, wave) -- the column scan walks A's sixteen rows, then B's: inside a
+// bucket all of A precedes all of B, the stable order -- and staged through the 128 KiB buffer in two halves BY POSITION
+// ([0, H) then [H, 2H), H = a tile's keys: whatever the keys are, a half fits), each half written out in quads like
+// scatter_msd_kernel does.  A run that straddles H is cut in two, like any run at a tile's end.
+template <uint32_t BITS>
+__device__ __forceinline__ void ScatterMsdPairBody(const MsdArgs a) {
+  constexpr int THREADS = 1024, KPT = 32, WAVES = THREADS / 64;
+  constexpr uint32_t TILE = kMsdTileKeys, D = 1u << BITS, ROW = D / 2u;
+  static_assert(2 * WAVES * ROW <= TILE, "both sub-tiles' counter rows inside the staging buffer");
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  uint32_t* const sorted = smem;               // TILE: half of the super-tile's keys at a time, regrouped by digit
+  uint32_t* const counters = smem;             // 2 x WAVES x ROW packed counters; dead before the first key is staged
+  uint32_t* const tileOffset = smem + TILE;    // D: global base - local base of the super-tile
+  uint32_t* const scanScratch = tileOffset + D;  // 32
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const uint32_t n = ElementCount(a.maxCount, a.countPtr);
+  const uint32_t pairs = (a.tiles + 1u) / 2u;
+  // XCD x takes the consecutive super-tiles [x C, (x + 1) C), C = ceil(pairs / 8) (scatter_msd_kernel)
+  const uint32_t perXcd = (pairs + 7u) / 8u;
+  const uint32_t pair = (blockIdx.x % 8u) * perXcd + blockIdx.x / 8u;
+  const uint32_t slots = a.tileKeys / (uint32_t)THREADS;
+  const uint32_t frame = a.tileKeys;          // H
+  const uint32_t decided = *a.overflowWord;
+  if ((decided & kMsdDeclineMask) != 0u) {
+    if (blockIdx.x == 0 && tid == 0 && a.declinedPlans != nullptr) atomicAdd(a.declinedPlans, 1u);
+    return;
+  }
+  const uint32_t SHIFT = (decided >> kMsdShiftShift) & kMsdShiftMask;
+  if (((decided >> kMsdModeShift) & kMsdModeMask) == kMsdModeIdentical) {
+    if (blockIdx.x == 0 && tid == 0) *a.planWord = kMsdVerdictSorted;
+    return;
+  }
+  const uint32_t tileA = 2u * pair;
+  const uint32_t startA = tileA * frame, startB = startA + frame;
+  const bool exists = blockIdx.x < 8u * perXcd && pair < pairs && startA < n;
+  const uint32_t left = exists ? n - startA : 0u;
+  const uint32_t validA = left < frame ? left : frame;
+  const uint32_t validB = left > frame ? (left - frame < frame ? left - frame : frame) : 0u;
+  const uint32_t valid = validA + validB;
+  const uint32_t baseA = startA + wave * (slots * 64) + lane, baseB = baseA + frame;
+  uint32_t keyA[KPT], keyB[KPT];
+  LoadStriped<KPT, VRDX_MSD_NT_LOADS != 0, true>(a.keysCaller, baseA, startA + validA, validA == frame, 0xFFFFFFFFu, keyA, slots);
+  LoadStriped<KPT, VRDX_MSD_NT_LOADS != 0, true>(a.keysCaller, baseB, startB + validB, validB == frame, 0xFFFFFFFFu, keyB, slots);
+  uint32_t prefixWord = 0, base0 = 0, base1 = 0;
+  if ((uint32_t)tid < ROW && valid != 0) {
+    prefixWord = a.tileCounts[(size_t)tileA * ROW + tid];
+    base0 = a.bucketBase[2 * tid];
+    base1 = a.bucketBase[2 * tid + 1];
+  }
+  if (blockIdx.x == 0 && tid == 0) *a.planWord = kMsdVerdictRuns | (SHIFT << kMsdShiftShift);
+  if (valid == 0) return;
+
+  uint32_t* const rowA = counters + wave * ROW;
+  uint32_t* const rowB = counters + (WAVES + wave) * ROW;
+#pragma unroll
+  for (uint32_t i = 0; i < ROW / 256u; ++i) {
+    reinterpret_cast<u32x4*>(rowA)[lane + 64 * i] = u32x4{0u, 0u, 0u, 0u};
+    reinterpret_cast<u32x4*>(rowB)[lane + 64 * i] = u32x4{0u, 0u, 0u, 0u};
+  }
+  uint32_t posA[KPT / 2], posB[KPT / 2];  // ranks, then positions inside the super-tile (< 65536), two to a register
+  RankPacked16<KPT, true>(keyA, SHIFT, BITS, rowA, lane, posA, slots);
+  ForgetDerivedValues<KPT>(keyA);
+  RankPacked16<KPT, true>(keyB, SHIFT, BITS, rowB, lane, posB, slots);
+  ForgetDerivedValues<KPT>(keyB);
+  LdsBarrier();
+
+  // the super-tile's histogram over all 32 rows (A's waves, then B's), its local bases, every row's first position per digit
+  const uint32_t totals = (uint32_t)tid < ROW ? ColumnTotals<ROW, 2 * WAVES>(counters, tid) : 0u;
+  const uint32_t count0 = totals & 0xFFFFu, count1 = totals >> 16;
+  const uint32_t local0 = BlockExclusiveScanAll<THREADS>(count0 + count1, scanScratch, tid);
+  const uint32_t local1 = local0 + count0;
+  if ((uint32_t)tid < ROW) {
+    ColumnBases<ROW, 2 * WAVES>(counters, tid, local0 | (local1 << 16));
+    tileOffset[2 * tid] = base0 + (prefixWord & 0xFFFFu) - local0;
+    tileOffset[2 * tid + 1] = base1 + (prefixWord >> 16) - local1;
+  }
+  LdsBarrier();
+  PositionsPacked16<KPT, TILE, true, true>(keyA, SHIFT, BITS, rowA, posA, slots);
+  PositionsPacked16<KPT, TILE, true, true>(keyB, SHIFT, BITS, rowB, posB, slots);
+  LdsBarrier();  // the counters are dead: the staging buffer takes their place
+
+  constexpr int QUADS = KPT / 4;
+  constexpr int B = 2;  // (four at a time: 128 registers and 48 bytes of scratch)
+  // the quads around a run's start, by the thread that owns the run (two runs per thread, scatter_msd_kernel)
+  uint32_t boundaryQuad[2] = {~0u, ~0u};
+  if ((uint32_t)tid < ROW) {
+    if (count0 != 0 && (local0 & 3u) != 0 && local0 < valid) boundaryQuad[0] = local0 & ~3u;
+    if (count1 != 0 && (local1 & 3u) != 0 && local1 < valid) boundaryQuad[1] = local1 & ~3u;
+  }
+  if (tid == 0 && (valid & 3u) != 0) boundaryQuad[0] = valid & ~3u;  // (digit 0 starts at 0: thread 0's first slot is free)
+#pragma unroll 1
+  for (uint32_t half = 0; half < 2; ++half) {
+    const uint32_t from = half * frame;  // positions [from, from + frame) go through the buffer now
+    if (from >= valid) break;
+    if (half != 0) LdsBarrier();         // every quad of the first half has been read
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      if (i % 4 == 0 && (uint32_t)i >= slots) break;
+      const uint32_t pa = ((posA[i / 2] >> (16 * (i % 2))) & 0xFFFFu) - from;
+      const uint32_t pb = ((posB[i / 2] >> (16 * (i % 2))) & 0xFFFFu) - from;
+      if (pa < frame) sorted[StagingSlot<TILE>(pa)] = keyA[i];
+      if (pb < frame) sorted[StagingSlot<TILE>(pb)] = keyB[i];
+    }
+    LdsBarrier();
+    const uint32_t here = valid - from < frame ? valid - from : frame;  // keys in the buffer
+#pragma unroll
+    for (int j0 = 0; j0 < QUADS; j0 += B) {
+      if (4u * (uint32_t)j0 * THREADS >= here) break;
+      u32x4 w4[B];
+      uint32_t o[B];
+      bool whole[B];
+#pragma unroll
+      for (int b = 0; b < B; ++b) w4[b] = *reinterpret_cast<const u32x4*>(&sorted[4u * (tid + (j0 + b) * THREADS)]);
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const uint32_t p = StagingSlot<TILE>(4u * (tid + (j0 + b) * THREADS));  // involution: the quad's position in this half
+        const uint32_t d0 = __builtin_amdgcn_ubfe(w4[b][0], SHIFT, BITS), d3 = __builtin_amdgcn_ubfe(w4[b][3], SHIFT, BITS);
+        whole[b] = p + 3 < here && d0 == d3;
+        o[b] = tileOffset[d0] + from + p;
+        asm volatile("" : "+v"(o[b]));
+      }
+#pragma unroll
+      for (int b = 0; b < B; ++b)
+        if (whole[b]) StoreQuad(a.keysScratch, o[b], w4[b]);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const uint32_t q0 = boundaryQuad[s] - from;  // (~0u - from: beyond `frame`)
+      if (boundaryQuad[s] == ~0u || q0 >= frame) continue;
+      const u32x4 q = *reinterpret_cast<const u32x4*>(&sorted[StagingSlot<TILE>(q0)]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (q0 + c < here) StoreWord(a.keysScratch, tileOffset[__builtin_amdgcn_ubfe(q[c], SHIFT, BITS)] + boundaryQuad[s] + c, q[c]);
+    }
+  }
+}
+template <uint32_t BITS>
+__global__ __launch_bounds__(1024) void scatter_msd_pair_kernel(MsdArgs a) {
+  ScatterMsdPairBody<BITS>(a);
 }
 
 // ---- bucket_sort2_kernel ----------------------------------------------------------------------------
@@ -3283,6 +3433,17 @@ hipError_t LaunchScatterMsd(hipStream_t stream, bool keyValue, const MsdArgs& ar
   }
   // a multiple of 8 workgroups: eight chunks of consecutive tiles, one per XCD (see the kernel)
   return Launch(kernel, 8u * ((args.tiles + 7u) / 8u), 1024, lds, stream, args);
+}
+
+hipError_t LaunchScatterMsdPair(hipStream_t stream, const MsdArgs& args) {
+  if (args.tileKeys == 0 || args.tileKeys % 4096u != 0 || args.tileKeys > kMsdTileKeys) return hipErrorInvalidValue;
+  const uint32_t pairs = (args.tiles + 1u) / 2u;
+  const size_t lds = ScatterMsdLdsWords<10>() * 4;
+  const void* kernel = reinterpret_cast<const void*>(&scatter_msd_pair_kernel<10>);
+  if (args.bits != 10) return hipErrorInvalidValue;
+  static const hipError_t raised = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (raised != hipSuccess) return raised;
+  return Launch(kernel, 8u * ((pairs + 7u) / 8u), 1024, lds, stream, args);
 }
 
 hipError_t LaunchBucketSort2(hipStream_t stream, bool keyValue, const MsdArgs& args) {
