@@ -405,7 +405,7 @@ int MsdParity(Harness& h, const std::vector<uint32_t>& wanted) {
     k24[n - 1] = 0x81234567u;
     run(Mode::KeyValue, k24, iota, n, "msd declines: prefix broken at n-1", 0);
     k24[n - 1] &= 0xFFFFFFu;
-    k24[n / 3] |= 0x01000000u;
+    k24[n / 3 + 7] |= 0x01000000u;  // (not one of the 64 sampled positions j (n - 1) / 63)
     run(Mode::Keys, k24, iota, n, "msd declines: prefix broken inside", 0);
     // 12-bit keys: ten bits of window, two bits for the local passes; 8-bit keys: at most 256 buckets can hold anything, which
     // at these sizes is more than they take -> turned down by the prologue

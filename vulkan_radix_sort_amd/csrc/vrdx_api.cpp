@@ -339,7 +339,6 @@ struct SortPlan {
   uint32_t msdTileKeys = 0;
   uint32_t msdTiles = 0;
   uint32_t msdFused = 0;        // how many of the plan's launches double as the fallback's first passes (0 | 1 | 2)
-  bool msdPair = false;         // VRDX_MSD_PAIR=1: the two-tile scatter kernel (measurements)
   int configIndex = 0;
   vrdx::TilePlan tilePlan{};
   bool blockSums = false;
@@ -399,9 +398,7 @@ SortPlan PlanSort(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCou
   // measured slower than the launches it saves, vrdx_kernels.hip); with buckets of the half-size kernel (512 threads; the
   // passes' bodies need 1024) only the scatter launch has a second role.  VRDX_MSD_FUSED=0: none (measurements).
   static const int fusedKnob = TuningKnob("VRDX_MSD_FUSED");
-  static const int pairKnob = TuningKnob("VRDX_MSD_PAIR");  // experiment: scatter_msd_pair_kernel (keys-only, ten bits; nothing fused)
-  p.msdPair = pairKnob > 0 && p.msdBits == 10 && !keyValue;
-  if (p.msdBits != 0 && !keyValue && p.configIndex == kCfg1024x32x2 && fusedKnob != 0 && !p.msdPair)
+  if (p.msdBits != 0 && !keyValue && p.configIndex == kCfg1024x32x2 && fusedKnob != 0)
     p.msdFused = p.msdCap == vrdx::kMsdCapKeys ? 2u : 1u;
   // kernels: histogram + four passes (+ the eight-bit plan's bucket launch); the MSD plan: + spine, and those of its scatter
   // and bucket launches that are not also a pass
@@ -629,8 +626,6 @@ void RecordSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t eleme
     Stamp(pool, query + 3, stream);
     if (msdFused >= 1)
       EnqueueCheck(sorter, "msd_scatter_or_pass0_kernel", vrdx::LaunchMsdFused(stream, false, keyValue, m, passArgs(0), tilePlan.tiles));
-    else if (plan.msdPair)
-      EnqueueCheck(sorter, "scatter_msd_pair_kernel", vrdx::LaunchScatterMsdPair(stream, m));
     else
       EnqueueCheck(sorter, "scatter_msd_kernel", vrdx::LaunchScatterMsd(stream, keyValue, m));
     Stamp(pool, query + 4, stream);

@@ -138,7 +138,8 @@ hipError_t LaunchBucketSort(hipStream_t stream, bool keyValue, bool atomicRank, 
 //   spine_msd_kernel      turns the counts, in place, into exclusive prefixes over the tiles and leaves every bucket's base;
 //                         a bucket beyond `cap` elements sets *overflowWord;
 //   scatter_msd_kernel    one stable scatter by the window bits, caller -> scratch: no ticket, no look-back, no status words --
-//                         a tile's bases are bucketBase[d] + its row of prefixes;
+//                         a tile's bases are bucketBase[d] + its row of prefixes; keys-only sorts take TWO consecutive tiles per
+//                         workgroup (round 6: runs of 256 bytes instead of 128);
 //   bucket_sort2_kernel   one workgroup per bucket sorts it by the bits below the window (none, one or two stable passes of
 //                         up to 11 bits) inside its LDS, scratch -> caller.
 // All of it with wave-private counters of 16 bits, two to a word.  The device decides (the overflow word): with a bucket
@@ -206,8 +207,6 @@ hipError_t PrepareMsd();
 hipError_t LaunchHistogramMsd(hipStream_t stream, uint32_t grid, const MsdArgs& args);
 hipError_t LaunchSpineMsd(hipStream_t stream, const MsdArgs& args);
 hipError_t LaunchScatterMsd(hipStream_t stream, bool keyValue, const MsdArgs& args);
-// (round 6, experiment: two tiles per workgroup, keys-only, ten bits -- runs of twice the length)
-hipError_t LaunchScatterMsdPair(hipStream_t stream, const MsdArgs& args);
 hipError_t LaunchBucketSort2(hipStream_t stream, bool keyValue, const MsdArgs& args);
 // The scatter (bucketLaunch = false) or bucket (true) launch of the plan with pass 0 / pass 1 of its fallback as a second
 // role, chosen on the device by the plan's verdict: saves two of the four returning launches.  `pass` = the arguments and

@@ -2555,8 +2555,9 @@ __device__ __forceinline__ void ScatterMsdBody(const MsdArgs a) {
   }
 }
 
-// ---- scatter_msd_pair_kernel (round 6, experiment: VRDX_MSD_PAIR=1) --------------------------------------
-// TWO consecutive tiles A, B per workgroup, keys-only.  What the scatter pays for is its write pattern: a tile of 32768 keys
+// ---- the keys-only scatter (round 6): two tiles per workgroup -----------------------------------------------
+// TWO consecutive tiles A, B per workgroup, keys-only (key+value sorts keep one tile per workgroup, above: two tiles' keys
+// AND values do not fit the register file).  What the scatter pays for is its write pattern: a tile of 32768 keys
 // over 1024 buckets writes runs of 128 bytes at 4-byte alignment, 1.45 x the bytes (profiles/r05_pmc_traffic.json).  In memory a
 // tile's run of bucket d is followed by the NEXT tile's run of bucket d (prefix[B][d] = prefix[A][d] + count[A][d]), so a
 // workgroup that holds both tiles writes ONE run of twice the length: both tiles' keys in registers (the two-sub-tile pass
@@ -2564,6 +2565,9 @@ __device__ __forceinline__ void ScatterMsdBody(const MsdArgs a) {
 // bucket all of A precedes all of B, the stable order -- and staged through the 128 KiB buffer in two halves BY POSITION
 // ([0, H) then [H, 2H), H = a tile's keys: whatever the keys are, a half fits), each half written out in quads like
 // scatter_msd_kernel does.  A run that straddles H is cut in two, like any run at a tile's end.
+// Measured against the one-tile form (profiles/r06_scatter_pair.txt, rocprofv3, ten sorts back to back): 70.4 instead of 83.0 us
+// at 2^25, 36.8 instead of 43.1 at 2^24; WRITE_SIZE 157.9 MB per launch instead of 193.2 (1.18 x instead of 1.44 x of what must
+// be written), reads unchanged.
 template <uint32_t BITS>
 __device__ __forceinline__ void ScatterMsdPairBody(const MsdArgs a) {
   constexpr int THREADS = 1024, KPT = 32, WAVES = THREADS / 64;
@@ -2699,9 +2703,16 @@ __device__ __forceinline__ void ScatterMsdPairBody(const MsdArgs a) {
     }
   }
 }
-template <uint32_t BITS>
-__global__ __launch_bounds__(1024) void scatter_msd_pair_kernel(MsdArgs a) {
-  ScatterMsdPairBody<BITS>(a);
+// The plan's scatter by mode: two tiles per workgroup for keys-only sorts by ten bits, one tile per workgroup otherwise
+// (key+value; eleven bits: with 1024-word counter rows the two-tile body needs 116 bytes of scratch per lane).
+template <uint32_t BITS, bool KV>
+constexpr bool MsdScatterTakesPairs() { return !KV && BITS == 10; }
+template <uint32_t BITS, bool KV>
+__device__ __forceinline__ void ScatterMsdRole(const MsdArgs a) {
+  if constexpr (MsdScatterTakesPairs<BITS, KV>())
+    ScatterMsdPairBody<BITS>(a);
+  else
+    ScatterMsdBody<BITS, KV>(a);
 }
 
 // ---- bucket_sort2_kernel ----------------------------------------------------------------------------
@@ -2882,7 +2893,7 @@ __device__ __forceinline__ void BucketSort2Body(const MsdArgs a) {
 
 template <uint32_t BITS, bool KV>
 __global__ __launch_bounds__(1024) void scatter_msd_kernel(MsdArgs a) {
-  ScatterMsdBody<BITS, KV>(a);
+  ScatterMsdRole<BITS, KV>(a);
 }
 template <uint32_t BITS, int KPT, bool KV>
 __global__ __launch_bounds__(1024) void bucket_sort2_kernel(MsdArgs a) {
@@ -2929,7 +2940,7 @@ constexpr size_t MsdFusedLdsWords(uint32_t bits, bool bucketLaunch) {
 template <uint32_t BITS, bool KV, bool DYN>
 __global__ __launch_bounds__(1024) void msd_scatter_or_pass0_kernel(MsdArgs m, OnesweepArgs p) {
   if ((*m.overflowWord & kMsdDeclineMask) == 0u) {
-    ScatterMsdBody<BITS, KV>(m);
+    ScatterMsdRole<BITS, KV>(m);
   } else {
     if (blockIdx.x == 0 && threadIdx.x == 0 && m.declinedPlans != nullptr) atomicAdd(m.declinedPlans, 1u);
     // (the grid is the larger of the two roles': a workgroup beyond the pass's tiles has no ticket to take)
@@ -3416,6 +3427,12 @@ hipError_t LaunchSpineMsd(hipStream_t stream, const MsdArgs& args) {
   return hipErrorInvalidValue;
 }
 
+// workgroups of the plan's scatter: one per tile, or per two tiles (keys-only, ten bits), rounded up to a multiple of 8
+static uint32_t MsdScatterGrid(uint32_t tiles, bool keyValue, uint32_t bits) {
+  const uint32_t units = !keyValue && bits == 10 ? (tiles + 1u) / 2u : tiles;
+  return 8u * ((units + 7u) / 8u);
+}
+
 hipError_t LaunchScatterMsd(hipStream_t stream, bool keyValue, const MsdArgs& args) {
   const void* kernel;
   size_t lds;
@@ -3431,19 +3448,8 @@ hipError_t LaunchScatterMsd(hipStream_t stream, bool keyValue, const MsdArgs& ar
   } else {
     return hipErrorInvalidValue;
   }
-  // a multiple of 8 workgroups: eight chunks of consecutive tiles, one per XCD (see the kernel)
-  return Launch(kernel, 8u * ((args.tiles + 7u) / 8u), 1024, lds, stream, args);
-}
-
-hipError_t LaunchScatterMsdPair(hipStream_t stream, const MsdArgs& args) {
-  if (args.tileKeys == 0 || args.tileKeys % 4096u != 0 || args.tileKeys > kMsdTileKeys) return hipErrorInvalidValue;
-  const uint32_t pairs = (args.tiles + 1u) / 2u;
-  const size_t lds = ScatterMsdLdsWords<10>() * 4;
-  const void* kernel = reinterpret_cast<const void*>(&scatter_msd_pair_kernel<10>);
-  if (args.bits != 10) return hipErrorInvalidValue;
-  static const hipError_t raised = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (raised != hipSuccess) return raised;
-  return Launch(kernel, 8u * ((pairs + 7u) / 8u), 1024, lds, stream, args);
+  // a multiple of 8 workgroups: eight chunks of consecutive tiles (keys-only: pairs of tiles), one per XCD (see the kernels)
+  return Launch(kernel, MsdScatterGrid(args.tiles, keyValue, args.bits), 1024, lds, stream, args);
 }
 
 hipError_t LaunchBucketSort2(hipStream_t stream, bool keyValue, const MsdArgs& args) {
@@ -3479,7 +3485,7 @@ static hipError_t LaunchMsdFusedBits(hipStream_t stream, bool bucketLaunch, cons
                           : reinterpret_cast<const void*>(&msd_scatter_or_pass0_kernel<BITS, KV, false>));
   // the larger of the two roles' grids, a multiple of 8 (the scatter derives its tile from the grid: eight chunks of tiles, one
   // per XCD; a workgroup beyond its role's range returns)
-  const uint32_t planGrid = bucketLaunch ? (1u << BITS) : 8u * ((m.tiles + 7u) / 8u);
+  const uint32_t planGrid = bucketLaunch ? (1u << BITS) : MsdScatterGrid(m.tiles, KV, BITS);
   const uint32_t grid = 8u * (((planGrid > passGrid ? planGrid : passGrid) + 7u) / 8u);
   // the pass's run-time slot counts, checked like LaunchPairConfig / LaunchConfig do
   if (dyn && (p.slots % 4 != 0 || p.slots > 32u || p.tailSlots % 4 != 0 || p.tailSlots == 0 || p.tailSlots > 32u))
