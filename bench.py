@@ -298,13 +298,15 @@ def priced_point(plan, taken, n, ms):
             "bytes_per_item": per_item, "hbm_fraction": per_item * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
 
 
-ADVERSARIAL_PATTERNS = ("uniform", "all-equal", "all-0xFFFFFFFF", "descending", "ascending", "few-distinct(4)", "24-bit")
+ADVERSARIAL_PATTERNS = ("uniform", "all-equal", "all-0xFFFFFFFF", "descending", "ascending", "few-distinct(4)", "24-bit",
+                        "bell-shaped top byte")
 
 
 def adversarial_block(torch, executor, sorter, pristine, n, device, runs=6):
     """BASELINE.json configs[3] / BASELINE.md section 3: N = 2^25 adversarial keys (all-equal, all-0xFFFFFFFF -- the
-    padding sentinel --, descending N-1-i, ascending, few-distinct: four values; and 24-bit keys like the reference's
-    DataGenerator::Generate(n, 24), bench/data_generator.cc:15), keys-only and key+value with values = iota.  Protocol of
+    padding sentinel --, descending N-1-i, ascending, few-distinct: four values; 24-bit keys like the reference's
+    DataGenerator::Generate(n, 24), bench/data_generator.cc:15; and mildly skewed keys, a bell-shaped top byte), keys-only
+    and key+value with values = iota.  Protocol of
     the size curve (bench/bench.cc:66-112: 1 warm-up + 5 timed runs, median GPU time between two events around the sort,
     input restored on the device before every run).  Per pattern and mode: GItems/s, slowdown against uniform keys in
     the same protocol, which sort ran (the device's verdict), and a proof of the permutation computed on the device:
@@ -333,6 +335,14 @@ def adversarial_block(torch, executor, sorter, pristine, n, device, runs=6):
             return four[(u & 3).to(torch.int64)]
         if pattern == "24-bit":
             return ((u.to(torch.int64) & 0xFFFFFFFF) >> 8).to(torch.int32)
+        if pattern == "bell-shaped top byte":
+            # mildly skewed keys (the mean of four uniform bytes in the top byte: the fullest ten-bit bucket holds 1.5 x the
+            # mean, more than the plan's buckets leave room for): what the device turns down by the COUNT, not by the sample
+            r = u.to(torch.int64) & 0xFFFFFFFF
+            top = ((r & 255) + ((r >> 8) & 255) + ((r >> 16) & 255) + (r >> 24)) >> 2
+            low = pristine[0][1][:n].to(torch.int64) & 0x00FFFFFF
+            k = (top << 24) | low
+            return torch.where(k >= (1 << 31), k - (1 << 32), k).to(torch.int32)
         raise ValueError(pattern)
 
     def unsigned(t):

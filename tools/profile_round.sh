@@ -38,6 +38,9 @@ ls -R $OUT | head -40
 # 5. the rest of the round's evidence: adversarial inputs at 2^25, a soak of overlapping sorts, the bench driver's sweep
 #    (hip and rocprim backends), the smoke entry and the GPU test log
 timeout 900 tests/native/vrdx_selftest adversarial 25 > $OUT/adversarial.txt 2>&1
+# ... and the same inputs with the four passes alone (VRDX_MSD=0), on the same box: what a plan that is turned down costs
+echo "# the same with VRDX_MSD=0 (the four passes alone)" >> $OUT/adversarial.txt
+VRDX_MSD=0 timeout 900 tests/native/vrdx_selftest adversarial 25 >> $OUT/adversarial.txt 2>&1
 timeout 300 tests/native/vrdx_selftest soak 120 > $OUT/soak.txt 2>&1
 if [ "${WITH_DRIVER:-0}" = 1 ]; then  # (ten minutes each: the reference's sweep, 64 sizes x 11 runs x fresh mt19937 data)
   timeout 900 bench/bench hip --no-verify -o $OUT/bench_driver_hip.csv > $OUT/bench_driver_hip.log 2>&1

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round 5, item 3 of the round-4 review: the ceiling of the pass-shaped kernels re-measured on the tree that ships.
+# NOTE (round 6): the VRDX_ABLATE sites this script builds with were removed from vrdx_kernels.hip; run it on the tree of commit 9caa359.
 # Builds timing-ablation variants of the library (VRDX_ABLATE, vrdx_kernels.hip) ON the box, runs the four-pass plan
 # (VRDX_MSD=0) at 2^25 under rocprofv3 for each, then the product at 2^26 and 2^27.  Writes gpurun_out/r05_ceiling/.
 set -u

@@ -55,13 +55,9 @@ namespace vrdx {
 #ifndef VRDX_NT_LAST_PASS
 #define VRDX_NT_LAST_PASS 0
 #endif
-// Timing ablations of the pass kernels (tools/r05/ceiling.sh; results are WRONG by construction, 0 in the product), the ones
-// round 2 measured the formulation's ceiling with: 1 = no look-back (the prefix is taken as zero), 8 = the tile id is the
-// workgroup's index instead of a ticket, 256 = every tile writes its own key range (contiguous stores; the offset lookup
-// is still made).  257 / 265 = "what a pass would cost with the look-back (and the ticket) free".
-#ifndef VRDX_ABLATE
-#define VRDX_ABLATE 0
-#endif
+// (The timing ablations round 5 measured the four-pass formulation's ceiling with -- VRDX_ABLATE: no look-back, no ticket,
+// contiguous stores; results wrong by construction -- are gone from the source: profiles/r05_ceiling.txt has the numbers, commit
+// 9caa359 the build.)
 // Measurement switches of the MSD plan's kernels (tools/r05/ablate.sh builds the variants): VRDX_MSD_XCD = 0: tiles handed
 // out round-robin instead of in consecutive chunks per XCD; VRDX_MSD_NT_LOADS / VRDX_MSD_BUCKET_NT: non-temporal loads in
 // the scatter / the bucket kernel.
@@ -1110,7 +1106,7 @@ __device__ __forceinline__ void OnesweepBody(const OnesweepArgs a) {
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   uint32_t key[KPT];
   const PassCounts<THREADS> passCounts = LoadPassCounts<THREADS>(a.histogramTable, tid);
-  if (tid == 0) misc[0] = (VRDX_ABLATE & 8) ? blockIdx.x : atomicAdd(a.ticketCur, 1u);
+  if (tid == 0) misc[0] = atomicAdd(a.ticketCur, 1u);
   PublishPassVotes<THREADS>(passCounts, n, a.hybridCap, tid, planFlags);
   // block sums (sorts of one round, four-pass plan only: the digit is the pass): every tile needs this pass's 256 global
   // counts for the digit base -- they are in the registers of the threads [256 * pass, 256 * pass + 256) already
@@ -1248,14 +1244,14 @@ __device__ __forceinline__ void OnesweepBody(const OnesweepArgs a) {
       exclusive += BlockPrefix<THREADS>(a.statusCur, a.blockCur, tile, tid, waveHist, a.failure, a.stickyFailure, a.spinLimit,
                                         &lookBackTrace);
   }
-  if (!blockSums && tile != 0 && !(VRDX_ABLATE & 1))
+  if (!blockSums && tile != 0)
     exclusive = LookBack<THREADS>(a.statusCur, tile, tid, waveHist, a.failure, a.stickyFailure, a.spinLimit, &lookBackTrace);
   TestDelayFirstTile(tile, a.spinLimit);
   if (tid < 256) {
     if (!lastTile && !blockSums)
       StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid],
                   (VRDX_FLAG_INCLUSIVE << VRDX_FLAG_SHIFT) | ((exclusive + count) & VRDX_VALUE_MASK));
-    tileOffset[tid] = (VRDX_ABLATE & 256) ? tileStart : exclusive - tileExclusive;
+    tileOffset[tid] = exclusive - tileExclusive;
   }
   LdsBarrier();
   VRDX_STAMP(5);
@@ -1367,7 +1363,7 @@ __device__ __forceinline__ void OnesweepPairBody(const OnesweepArgs a) {
   if (a.planInFront != 0 && (*a.planWord & kMsdVerdictMask) >= kMsdVerdictRuns) return;  // the MSD plan has taken the sort (see onesweep_kernel)
   const uint32_t n = ElementCount(a.maxCount, a.countPtr);
   const PassCounts<THREADS> passCounts = LoadPassCounts<THREADS>(a.histogramTable, tid);
-  if (tid == 0) misc[0] = (VRDX_ABLATE & 8) ? blockIdx.x : atomicAdd(a.ticketCur, 1u);
+  if (tid == 0) misc[0] = atomicAdd(a.ticketCur, 1u);
   PublishPassVotes<THREADS>(passCounts, n, a.hybridCap, tid, misc + 1);
   // block sums (see onesweep_kernel): this pass's 256 global counts, parked in the idle staging buffer
   const bool blockSums = THREADS == 1024 && a.blockCur != nullptr;
@@ -1503,7 +1499,7 @@ __device__ __forceinline__ void OnesweepPairBody(const OnesweepArgs a) {
       exclusive += BlockPrefix<THREADS>(a.statusCur, a.blockCur, tile, tid, lookScratch, a.failure, a.stickyFailure,
                                         a.spinLimit, &lookBackTrace);
   }
-  if (!blockSums && tile != 0 && !(VRDX_ABLATE & 1))
+  if (!blockSums && tile != 0)
     exclusive = LookBack<THREADS>(a.statusCur, tile, tid, lookScratch, a.failure, a.stickyFailure, a.spinLimit,
                                   &lookBackTrace);
   TestDelayFirstTile(tile, a.spinLimit);
@@ -1511,8 +1507,8 @@ __device__ __forceinline__ void OnesweepPairBody(const OnesweepArgs a) {
     if (!lastTile && !blockSums)
       StoreStatus(&a.statusCur[tile * VRDX_RADIX + tid],
                   (VRDX_FLAG_INCLUSIVE << VRDX_FLAG_SHIFT) | ((exclusive + countA + countB) & VRDX_VALUE_MASK));
-    offsetA[tid] = (VRDX_ABLATE & 256) ? tileStart : exclusive - localA;
-    offsetB[tid] = (VRDX_ABLATE & 256) ? tileStart + sub : exclusive + countA - localB;
+    offsetA[tid] = exclusive - localA;
+    offsetB[tid] = exclusive + countA - localB;
   }
   LdsBarrier();
   VRDX_STAMP(5);
