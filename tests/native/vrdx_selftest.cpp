@@ -721,7 +721,10 @@ int Adversarial(Harness& h, int lg) {
   constexpr int kPatterns = 11;
   double base[2] = {0, 0};
   int failures = 0;
-  std::printf("%-18s %-5s %10s %12s %10s %-8s %s\n", "keys", "sort", "gpu_ms", "GItems/s", "slowdown", "parity", "verdict");
+  std::printf("%-18s %-5s %10s %12s %10s %-8s %-8s %9s\n", "keys", "sort", "gpu_ms", "GItems/s", "slowdown", "parity", "verdict", "unstamped");
+  hipEvent_t bare0 = nullptr, bare1 = nullptr;
+  HIP_OK(hipEventCreate(&bare0));
+  HIP_OK(hipEventCreate(&bare1));
   const char* const patternsEnv = std::getenv("VRDX_SELFTEST_PATTERNS");  // the first k input patterns only
   const int patterns = patternsEnv != nullptr ? std::min(kPatterns, std::max(1, std::atoi(patternsEnv))) : kPatterns;
   for (int pattern = 0; pattern < patterns; ++pattern) {
@@ -748,20 +751,32 @@ int Adversarial(Harness& h, int lg) {
     std::vector<uint32_t> ek = k, ev = iota;
     vrdx_oracle_sort(ek.data(), ev.data(), n, nullptr);
     for (int kv = 0; kv < 2; ++kv) {
-      std::vector<uint64_t> times;
+      std::vector<uint64_t> times, bare;
       bool ok = true;
       uint32_t verdict = 0;
       double stageHist = 0, stagePass[4] = {0, 0, 0, 0};
-      for (int run = 0; run < 6; ++run) {
+      // runs 0-5: with the 15 timestamps (gpu_ms of run 0 is dropped; run 5 gives the stages); runs 6-10: WITHOUT them, two
+      // events around the sort -- the figure that compares plans fairly (a plan with more stages carries more event records)
+      for (int run = 0; run < 11; ++run) {
         HIP_OK(hipMemcpy(h.dKeys, k.data(), (size_t)n * 4, hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(h.dKeys + inout, iota.data(), (size_t)n * 4, hipMemcpyHostToDevice));
         HIP_OK(hipDeviceSynchronize());
+        const bool stamped = run < 6;
+        if (!stamped) HIP_OK(hipEventRecord(bare0, h.stream));
         if (kv)
           vrdxCmdSortKeyValue((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dKeys, inout,
-                              (VkBuffer)h.dStorage, StorageOffset(), h.pool, 0);
+                              (VkBuffer)h.dStorage, StorageOffset(), stamped ? h.pool : VK_NULL_HANDLE, 0);
         else
-          vrdxCmdSort((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dStorage, StorageOffset(), h.pool, 0);
+          vrdxCmdSort((VkCommandBuffer)h.stream, h.sorter, n, (VkBuffer)h.dKeys, 0, (VkBuffer)h.dStorage, StorageOffset(),
+                      stamped ? h.pool : VK_NULL_HANDLE, 0);
+        if (!stamped) HIP_OK(hipEventRecord(bare1, h.stream));
         HIP_OK(hipStreamSynchronize(h.stream));
+        if (!stamped) {
+          float msBare = 0;
+          HIP_OK(hipEventElapsedTime(&msBare, bare0, bare1));
+          bare.push_back((uint64_t)(msBare * 1e6));
+          continue;
+        }
         uint64_t ts[15];
         if (vrdxHipGetQueryPoolResults(h.pool, 0, 15, ts) != VK_SUCCESS) return 3;
         if (run > 0) times.push_back(ts[14]);
@@ -778,13 +793,13 @@ int Adversarial(Harness& h, int lg) {
           verdict = vrdxHipReadPlanVerdict((VkCommandBuffer)h.stream, (VkBuffer)h.dStorage, StorageOffset());
         }
       }
-      const double ms = Median(times) / 1e6;
+      const double ms = Median(times) / 1e6, msBare = Median(bare) / 1e6;
       if (pattern == 0) base[kv] = ms;
       if (!ok) ++failures;
-      std::printf("%-18s %-5s %10.4f %12.3f %9.2fx %-8s %-8s hist %.4f | passes %.4f %.4f %.4f %.4f\n", names[pattern],
+      std::printf("%-18s %-5s %10.4f %12.3f %9.2fx %-8s %-8s %9.4f  hist %.4f | passes %.4f %.4f %.4f %.4f\n", names[pattern],
                   kv ? "kv" : "keys", ms, n / (ms * 1e-3) / 1e9, ms / base[kv], ok ? "ok" : "MISMATCH",
                   verdict == VRDX_HIP_VERDICT_MSD_RUNS ? "msd" : verdict == VRDX_HIP_VERDICT_MSD_SORTED ? "sorted" : "passes",
-                  stageHist, stagePass[0], stagePass[1], stagePass[2], stagePass[3]);
+                  msBare, stageHist, stagePass[0], stagePass[1], stagePass[2], stagePass[3]);
       std::fflush(stdout);
     }
   }

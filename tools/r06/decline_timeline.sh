@@ -1,5 +1,5 @@
 #!/bin/bash
-# Kernel-by-kernel timeline of the adversarial inputs at 2^25 (the LAST of the six sorts of every pattern x mode), with the
+# Kernel-by-kernel timeline of the adversarial inputs at 2^25 (the LAST of the eleven sorts of every pattern x mode: no timestamps), with the
 # MSD plan recorded in front of the passes and with VRDX_MSD=0: what does a plan that the device turns down cost, and where?
 ROOT=$(cd "$(dirname "$0")/../.." && pwd); OUT=$ROOT/gpurun_out/${TAG:-r06_decline}; mkdir -p $OUT
 export TMPDIR=/tmp
@@ -21,13 +21,14 @@ for k, si in enumerate(starts):
     first = si - 1 if si > 0 and ("fill" in seq[si - 1][0].lower() or "prologue" in seq[si - 1][0]) else si
     body = [s for s in seq[first:end] if not ("fill" in s[0].lower() and s is not seq[first])]
     sorts.append(body)
-# six sorts per (pattern, mode); print the last of each group
-for g in range(0, len(sorts), 6):
-    grp = sorts[g:g + 6]
-    if len(grp) < 6: break
+# eleven sorts per (pattern, mode): six with the 15 timestamps, five without; print the last (unstamped) of each group
+G = 11
+for g in range(0, len(sorts), G):
+    grp = sorts[g:g + G]
+    if len(grp) < G: break
     body = grp[-1]
     t0 = body[0][1]; prev = None
-    print(f"--- sort group {g // 6} (pattern {g // 12}, {'kv' if (g // 6) % 2 else 'keys'})")
+    print(f"--- sort group {g // G} (pattern {g // (2 * G)}, {'kv' if (g // G) % 2 else 'keys'})")
     for n, s, e, grid, lds in body:
         gap = (s - prev) / 1e3 if prev else 0.0
         print(f"{n[:64]:64s} start {(s - t0)/1e3:8.2f} dur {(e - s)/1e3:7.2f} gap {gap:5.2f} grid {grid} lds {lds}")
