@@ -265,8 +265,9 @@ uint32_t vrdxHipReadPlanVerdict(VkCommandBuffer commandBuffer, VkBuffer storageB
  * recorded) and how many of those the device turned down (*pDeclined, counted on the device when the sort runs: a bucket
  * beyond the capacity, a key outside the sampled prefix, a sample that rules the plan out) -- such sorts run the four
  * passes and cost 1.3-1.5x the plan.  Uniform keys at the very top of a plan's size range are turned down with small
- * probability by design (3-4 % of headroom); a caller that sees the ratio rise knows its keys are skewed.  Synchronises
- * the stream; either pointer may be NULL. */
+ * probability by design (3-4 % of headroom); a caller that sees the ratio rise knows its keys are skewed.  (A sort captured
+ * into a hipGraph is recorded once and may run many times: every replay that is turned down counts.)  Synchronises the
+ * stream; either pointer may be NULL. */
 VkResult vrdxHipReadPlanCounters(VrdxSorter sorter, VkCommandBuffer commandBuffer, uint32_t* pRecorded, uint32_t* pDeclined);
 
 /* Library build info: "vrdx-hip <version> gfx950 tiles at 2^25: keys=<threads>x<keys per thread>[x<sub-tiles>]

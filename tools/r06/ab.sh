@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the round-5 tree: `git worktree add build/r05tree a7fc09d`, then `make -C vulkan_radix_sort_amd/csrc && make -C oracle &&
+#  make -C tests/native vrdx_selftest` inside it, here, before the gpurun call: build/ travels with the snapshot)
 # A/B on ONE box: the round-5 tree (git worktree build/r05tree, built there) against the working tree.
 # usage: ab.sh [log2n ...]   -> gpurun_out/$TAG/{old,new}_*.txt
 ROOT=$(cd "$(dirname "$0")/../.." && pwd); OUT=$ROOT/gpurun_out/${TAG:-r06_ab}; mkdir -p $OUT

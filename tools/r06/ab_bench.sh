@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the round-5 tree: `git worktree add build/r05tree a7fc09d`, then `make -C vulkan_radix_sort_amd/csrc && make -C oracle &&
+#  make -C tests/native vrdx_selftest` inside it, here, before the gpurun call: build/ travels with the snapshot)
 # A/B on ONE box in the reference protocol (`vrdx_selftest bench`: 1 warm-up + 10 timed sorts of fresh data, median GPU time):
 # the round-5 tree (git worktree build/r05tree, built there) against the working tree, alternating, three times.
 # usage: ab_bench.sh [log2n ...]

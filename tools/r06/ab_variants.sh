@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the round-5 tree: `git worktree add build/r05tree a7fc09d`, then `make -C vulkan_radix_sort_amd/csrc && make -C oracle &&
+#  make -C tests/native vrdx_selftest` inside it, here, before the gpurun call: build/ travels with the snapshot)
 # Per-kernel averages (rocprofv3, ten sorts back to back at 2^25) of the round-5 tree, the working tree and its compile-time
 # variants under build/variants/<name>/ (tools/build_variants.sh), all on ONE box.
 ROOT=$(cd "$(dirname "$0")/../.." && pwd); OUT=$ROOT/gpurun_out/${TAG:-r06_abv}; mkdir -p $OUT
