@@ -1,5 +1,6 @@
 #!/bin/bash
 # The two-tile scatter (scatter_msd_pair_kernel, VRDX_MSD_PAIR=1) against the shipped one-tile scatter (VRDX_MSD_FUSED=0, so that
+# NOTE: run on commit f1a3069, where the two-tile scatter is an experiment behind VRDX_MSD_PAIR=1 next to the one-tile form; from da5c39e on it IS the keys-only scatter.
 # both run as kernels of their own): parity battery, kernel durations (rocprofv3 --kernel-trace --stats, ten keys-only sorts back to
 # back), HBM bytes per launch (--pmc FETCH_SIZE / WRITE_SIZE in passes of their own).  -> gpurun_out/r06_pair/
 ROOT=$(cd "$(dirname "$0")/../.." && pwd); OUT=$ROOT/gpurun_out/${TAG:-r06_pair}; mkdir -p $OUT
