@@ -55,8 +55,10 @@ int main() {
           uint32_t bits = 0;
           for (uint32_t b = 10; b <= 11 && bits == 0; ++b)
             if ((((uint64_t)n + (1u << b) - 1) >> b) * 103 / 100 <= 36864) bits = b;
-          // (equal tiles filling whole rounds of one workgroup per CU: up to rounds x cus of them)
-          const uint32_t msdTileKeys = vrdx::MsdTileKeysFor(n, cus, 2048u);
+          // (equal tiles filling whole rounds of one workgroup per CU: up to rounds x cus of them; keys-only sorts by ten bits
+          // fill whole rounds of PAIRS of tiles: smaller tiles, a larger table)
+          for (int two = 0; two < (bits == 10 ? 2 : 1); ++two) {
+          const uint32_t msdTileKeys = vrdx::MsdTileKeysFor(n, cus, 2048u, two != 0);
           const uint64_t msdTiles = vrdx::RoundUp(n, msdTileKeys);
           ok = ok && msdTileKeys % 4096u == 0 && msdTileKeys >= 4096u && msdTileKeys <= 32768u && msdTiles <= 2048u;
           for (uint32_t address = 0; bits != 0 && address < 128; address += 16) {
@@ -71,6 +73,7 @@ int main() {
             ok = ok && lm.statusOffset == lm.msdCountsOffset + lm.msdCountsBytes && (address + lm.statusOffset) % 128 == 0;
             ok = ok && lm.statusClearOffset == lm.statusOffset && lm.statusClearBytes == lm.regionBytes;
             ok = ok && (address + lm.inoutOffset) % 128 == 0 && lm.valuesOffset >= lm.inoutOffset + (uint64_t)n * 4;
+          }
           }
         }
         for (uint32_t address = 0; address < 128; address += 16) {

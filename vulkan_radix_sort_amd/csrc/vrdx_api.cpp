@@ -217,9 +217,10 @@ uint32_t HybridCapacity(bool atomicRank, uint32_t elementCount) {
 // records it from n elements up instead (measurements: below its default range it replaces the other two plans).
 // Keys per tile of the MSD plan's histogram and scatter: equal tiles that fill whole rounds of one workgroup per CU
 // (vrdx_layout.h).  VRDX_MSD_EVEN=0: tiles of full capacity (measurements).
-uint32_t MsdTileKeys(uint32_t elementCount, uint32_t cus) {
+// twoPerWorkgroup: keys-only sorts by ten bits (their scatter takes two consecutive tiles per workgroup, vrdx_kernels.hip)
+uint32_t MsdTileKeys(uint32_t elementCount, uint32_t cus, bool twoPerWorkgroup) {
   static const int even = TuningKnob("VRDX_MSD_EVEN");
-  return even == 0 ? vrdx::kMsdTileKeys : vrdx::MsdTileKeysFor(elementCount, cus, vrdx::kMsdMaxTiles);
+  return even == 0 ? vrdx::kMsdTileKeys : vrdx::MsdTileKeysFor(elementCount, cus, vrdx::kMsdMaxTiles, twoPerWorkgroup);
 }
 
 uint32_t MsdBits(bool atomicRank, bool keyValue, uint32_t elementCount, uint32_t hybridCap, uint32_t* capacity) {
@@ -368,7 +369,7 @@ SortPlan PlanSort(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCou
   // VRDX_BLOCK_SUMS=0 keeps the classic look-back (measurements).
   static const int blockSumsKnob = TuningKnob("VRDX_BLOCK_SUMS");
   p.blockSums = p.tilePlan.blockSums && p.hybridCap == 0 && blockSumsKnob != 0;
-  p.msdTileKeys = MsdTileKeys(elementCount, (uint32_t)sorter->computeUnits);
+  p.msdTileKeys = MsdTileKeys(elementCount, (uint32_t)sorter->computeUnits, !keyValue && p.msdBits == 10);
   p.msdTiles = vrdx::RoundUp(elementCount, p.msdTileKeys);
   const uint32_t align = sorter->minStorageBufferOffsetAlignment;
   p.layout = vrdx::MakeLayout(elementCount, align, p.tilePlan.tiles, storageAddress, p.blockSums, p.msdBits, p.msdTiles);

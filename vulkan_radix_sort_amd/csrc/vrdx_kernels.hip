@@ -2038,7 +2038,11 @@ __global__ __launch_bounds__(kHistThreads) void histogram_msd_kernel(MsdArgs a) 
   // of 64 keys per wave, MsdTileKeysFor in vrdx_layout.h)
   static_assert(kHistThreads == 1024, "a row of vectors per load instruction");
   constexpr uint32_t D = 1u << BITS;
-  constexpr uint32_t TC = kMsdTopBinWords / D;        // replicas of a window bin
+  // The window bins are DOUBLE-BUFFERED (round 6): a tile counts into one half of the 32 KiB while the previous tile's half is
+  // summed, written out and cleared by the first D / 2 threads -- one barrier per tile instead of two, and the other waves do
+  // not wait for the flush.  (With one buffer the kernel stood still four times per workgroup at 2^25.)
+  constexpr uint32_t kTopHalf = kMsdTopBinWords / 2;  // words per buffer
+  constexpr uint32_t TC = kTopHalf / D;               // replicas of a window bin: 4 | 2
   constexpr uint32_t kByteWords = 3u * VRDX_RADIX * COPIES;
   constexpr uint32_t C3 = HistMsdByte3Copies(COPIES); // replicas of byte 3's own table (PREFIXED)
   constexpr uint32_t PER_BYTE = D / 256u;             // buckets per value of byte 3 when the window is at the top: 4 | 8
@@ -2046,7 +2050,8 @@ __global__ __launch_bounds__(kHistThreads) void histogram_msd_kernel(MsdArgs a) 
   enum : uint32_t { TOP = 0, PREFIXED = 1, TABLES = 2 };
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* const bins = smem;                        // [3][256][COPIES]
-  uint32_t* const top = smem + kByteWords;            // [D][TC]; TABLES: byte 3's [256][COPIES]
+  uint32_t* const top = smem + kByteWords;            // [2][D][TC]; TABLES: byte 3's [256][COPIES]
+  uint32_t* window = top;                             // the buffer the current tile counts in
   uint32_t* const bucketSize = top + kMsdTopBinWords; // [D]: this workgroup's share of every bucket, word pairs owned by one thread
   uint32_t* const byte3 = bucketSize + D;             // PREFIXED: [256][C3]
   uint32_t* const verdict = byte3 + VRDX_RADIX * C3;  // [2]: wave 0's conclusion from the sample, the reference key
@@ -2120,7 +2125,7 @@ __global__ __launch_bounds__(kHistThreads) void histogram_msd_kernel(MsdArgs a) 
       uint32_t t[NK];
 #pragma unroll
       for (uint32_t i = 0; i < NK; ++i) t[i] = FORM == TOP ? key[i] >> (32u - BITS) : (key[i] >> shift) & (D - 1u);
-      addShared(nk, top, t, TC);
+      addShared(nk, window, t, TC);
     }
   };
   constexpr std::integral_constant<uint32_t, 1> kOne{};
@@ -2145,24 +2150,29 @@ __global__ __launch_bounds__(kHistThreads) void histogram_msd_kernel(MsdArgs a) 
       }
     }
   };
-  // the tile's counts out, added to the workgroup's bucket sizes, the bins cleared
-  auto flush = [&](uint32_t tile) {
+  // the tile's counts out, added to the workgroup's bucket sizes, its buffer cleared -- by the first D / 2 threads, behind ONE
+  // barrier (every wave has counted the tile); the buffer is counted in again two tiles on, i.e. behind the next tile's barrier
+  auto flush = [&](uint32_t tile, uint32_t* counted) {
     LdsBarrier();
     for (uint32_t w = tid; w < D / 2; w += kHistThreads) {  // whole waves: D / 2 is a multiple of 64
+      uint32_t* const mine = counted + (size_t)w * 2u * TC;  // bins 2 w and 2 w + 1, TC replicas each
       uint32_t lo = 0, hi = 0;
-      u32x4* const mine = reinterpret_cast<u32x4*>(top + (size_t)w * 2u * TC);
-#pragma unroll
-      for (uint32_t q = 0; q < TC / 4; ++q) {
-        const u32x4 x = mine[q], y = mine[TC / 4 + q];
-        lo += x[0] + x[1] + x[2] + x[3];
-        hi += y[0] + y[1] + y[2] + y[3];
+      if constexpr (TC == 4) {
+        const u32x4 x = reinterpret_cast<const u32x4*>(mine)[0], y = reinterpret_cast<const u32x4*>(mine)[1];
+        lo = x[0] + x[1] + x[2] + x[3];
+        hi = y[0] + y[1] + y[2] + y[3];
+        reinterpret_cast<u32x4*>(mine)[0] = u32x4{0u, 0u, 0u, 0u};
+        reinterpret_cast<u32x4*>(mine)[1] = u32x4{0u, 0u, 0u, 0u};
+      } else {
+        static_assert(TC == 2 || TC == 4, "two bins of a thread are one or two 16-byte vectors");
+        const u32x4 x = reinterpret_cast<const u32x4*>(mine)[0];
+        lo = x[0] + x[1];
+        hi = x[2] + x[3];
+        reinterpret_cast<u32x4*>(mine)[0] = u32x4{0u, 0u, 0u, 0u};
       }
-#pragma unroll
-      for (uint32_t q = 0; q < TC / 2; ++q) mine[q] = u32x4{0u, 0u, 0u, 0u};
       a.tileCounts[(size_t)tile * (D / 2) + w] = lo | (hi << 16);
       reinterpret_cast<u32x2*>(bucketSize)[w] += u32x2{lo, hi};
     }
-    LdsBarrier();
   };
 
   const uint32_t nvec = n >> 2;
@@ -2173,7 +2183,10 @@ __global__ __launch_bounds__(kHistThreads) void histogram_msd_kernel(MsdArgs a) 
     const bool two = rows > 4;  // (uniform) tiles of more than four rows keep a second set of loads in flight
     // the first loads (and wave 0's sample in front of them) fly while the counters are cleared
     fetch(streaming, tile, 0, nvec, a4);
-    if (two) fetch(streaming, tile, 4, nvec, b4);
+    if (two)
+      fetch(streaming, tile, 4, nvec, b4);
+    else
+      fetch(streaming, tile + step, 0, nvec, b4);  // (tiles of at most four rows: the second set is the workgroup's NEXT tile)
     static_assert((kByteWords + kMsdTopBinWords + D) % 4u == 0, "cleared sixteen bytes at a time");
     for (uint32_t i = tid; i < (kByteWords + kMsdTopBinWords + D) / 4u; i += kHistThreads)
       reinterpret_cast<u32x4*>(bins)[i] = u32x4{0u, 0u, 0u, 0u};
@@ -2183,22 +2196,22 @@ __global__ __launch_bounds__(kHistThreads) void histogram_msd_kernel(MsdArgs a) 
       const uint32_t varying = differ != 0u ? 32u - (uint32_t)__clz((int)differ) : 0u;  // they all lie below this bit
       // (never lower than bit 2: each of the bucket kernel's two passes then has a bit to rank by, and keys of twelve bits
       // and fewer, for which that costs buckets, are rare at these sizes and quick in the four passes, two of which are trivial)
-      const uint32_t window = (varying > BITS + 2u ? varying : BITS + 2u) - BITS;
-      const uint32_t spread = varying > window ? varying - window : 0u;  // bits of the window that vary: <= BITS
+      const uint32_t lowest = (varying > BITS + 2u ? varying : BITS + 2u) - BITS;  // the window's lowest bit
+      const uint32_t spread = varying > lowest ? varying - lowest : 0u;  // bits of the window that vary: <= BITS
       uint32_t kind = kMsdModePlan;
       if (n != 0u && varying == 0u) {
         kind = kMsdModeIdentical;
       } else if (spread < BITS && (uint64_t)n > ((uint64_t)a.cap << spread)) {
         kind = kMsdModeDeclined;  // at most 2^spread buckets can hold anything
       } else {
-        uint32_t* const bin = &top[__builtin_amdgcn_ubfe(sampled, window, BITS) * TC];
+        uint32_t* const bin = &top[__builtin_amdgcn_ubfe(sampled, lowest, BITS) * TC];
         const uint32_t seen = atomicAdd(bin, 1u) + 1u;
         // (the estimate as well: a short indirect count samples every key many times)
         if (__ballot(seen >= kMsdSampleSkew && (uint64_t)seen * n / kMsdSampleKeys > a.cap) != 0ull) kind = kMsdModeDeclined;
         *bin = 0u;  // (behind every lane's atomic: LDS operations of one wave are carried out in order)
       }
       if (tid == 0) {
-        verdict[0] = (window << kMsdShiftShift) | (kind << kMsdModeShift) | (kind == kMsdModeDeclined ? kMsdDeclineSample : 0u);
+        verdict[0] = (lowest << kMsdShiftShift) | (kind << kMsdModeShift) | (kind == kMsdModeDeclined ? kMsdDeclineSample : 0u);
         verdict[1] = sampled;
       }
     }
@@ -2216,19 +2229,34 @@ __global__ __launch_bounds__(kHistThreads) void histogram_msd_kernel(MsdArgs a) 
         for (uint32_t i = tid; i < VRDX_RADIX * C3; i += kHistThreads) byte3[i] = 0;
         LdsBarrier();
       }
-      for (; tile < tiles; tile += step) {
-        tally(formTag, tile, 0, a4, nvec);
-        fetch(streaming, tile + step, 0, nvec, a4);
-        if (two) {
-          tally(formTag, tile, 4, b4, nvec);
-          fetch(streaming, tile + step, 4, nvec, b4);
-        }
-        // the last one to three keys belong to the tile that holds key n - 1
-        if (tile == nvec / tileVecs && tid < (n & 3u)) {
+      // the end of a tile: the last one to three keys belong to the tile that holds key n - 1; its counts out
+      auto finish = [&](uint32_t done) {
+        if (done == nvec / tileVecs && tid < (n & 3u)) {
           const uint32_t one[1] = {keys[(nvec << 2) + tid]};
           count(formTag, kOne, one);
         }
-        if constexpr (FORM != TABLES) flush(tile);
+        if constexpr (FORM != TABLES) {
+          flush(done, window);
+          window = window == top ? top + kTopHalf : top;
+        }
+      };
+      if (two) {  // tiles of five to eight rows: both sets of loads belong to one tile
+        for (; tile < tiles; tile += step) {
+          tally(formTag, tile, 0, a4, nvec);  // (counts into `window`)
+          fetch(streaming, tile + step, 0, nvec, a4);
+          tally(formTag, tile, 4, b4, nvec);
+          fetch(streaming, tile + step, 4, nvec, b4);
+          finish(tile);
+        }
+      } else {    // tiles of at most four rows: a set of loads per tile, two tiles in flight
+        for (; tile < tiles; tile += 2 * step) {
+          tally(formTag, tile, 0, a4, nvec);
+          fetch(streaming, tile + 2 * step, 0, nvec, a4);
+          finish(tile);
+          tally(formTag, tile + step, 0, b4, nvec);  // (beyond the last tile: every lane masked)
+          fetch(streaming, tile + 3 * step, 0, nvec, b4);
+          if (tile + step < tiles) finish(tile + step);
+        }
       }
     };
     if (form == TOP)

@@ -171,10 +171,14 @@ static inline bool LayoutFits(const StorageLayout& l, uint32_t maxElementCount) 
 // rounds of `cus` tiles: keys per tile, a multiple of 4096 (four 64-key slots per wave of its 1024 threads), at most 32768.
 // 520 tiles of 32768 keys would cost three rounds, the third for eight tiles; 768 tiles of 24576 cost three rounds of three
 // quarters the length.  maxTiles: the spine kernel's reach; beyond it, tiles of full capacity.
-static inline uint32_t MsdTileKeysFor(uint32_t elementCount, uint32_t cus, uint32_t maxTiles) {
+// twoPerWorkgroup (round 6: keys-only sorts by ten bits, whose scatter takes two consecutive tiles per workgroup): the tiles
+// fill whole rounds of `cus` PAIRS -- 2 x rounds x cus tiles -- so that a sort of 8.4 M keys is 256 workgroups of two tiles of
+// 16384 and not 128 of two of 32768 on half the CUs.
+static inline uint32_t MsdTileKeysFor(uint32_t elementCount, uint32_t cus, uint32_t maxTiles, bool twoPerWorkgroup = false) {
   if (elementCount == 0 || cus == 0) return 32768u;
-  const uint32_t rounds = RoundUp(elementCount, cus * 32768u);
-  uint32_t keys = 4096u * RoundUp(RoundUp(elementCount, rounds * cus), 4096u);
+  const uint32_t perWorkgroup = twoPerWorkgroup ? 2u : 1u;
+  const uint32_t rounds = RoundUp(elementCount, cus * 32768u * perWorkgroup);
+  uint32_t keys = 4096u * RoundUp(RoundUp(elementCount, rounds * cus * perWorkgroup), 4096u);
   if (keys > 32768u) keys = 32768u;
   return RoundUp(elementCount, keys) <= maxTiles ? keys : 32768u;
 }
