@@ -667,12 +667,17 @@ def main():
     plan_kv, kernels_kv = kernels_of(stamped_kv, True)
     # The whole sort is priced with the bytes of the plan that RAN in the timed region -- proven, not assumed: uniform keys
     # must have taken the plan the host recorded in every one of its sorts (the device counts the plans it turns down).
+    # (Should the device ever turn the plan down on these keys -- it cannot at 2^25: the capacity is 22 sigma above the mean
+    # bucket -- the line is still printed, priced with the four passes' bytes, and says so: `plan_proof`.)
+    def ran_as_recorded(plan, proof):
+        return plan.name not in ("msd", "hybrid-8") or (proof["plan_taken_by_last_sort"] and
+                                                        (plan.name != "msd" or proof["msd_plans_declined_in_timed_region"] == 0))
     for mode, plan, proof in (("keys-only", plan_keys, proof_keys), ("key+value", plan_kv, proof_kv)):
-        if plan.name in ("msd", "hybrid-8") and (not proof["plan_taken_by_last_sort"] or
-                                                  (plan.name == "msd" and proof["msd_plans_declined_in_timed_region"] != 0)):
-            raise RuntimeError(f"{mode}: the device turned the recorded {plan.name} plan down on uniform keys: {proof}")
-    bytes_keys = bytes_moved_per_item(plan_keys, proof_keys["plan_taken_by_last_sort"])
-    bytes_kv = bytes_moved_per_item(plan_kv, proof_kv["plan_taken_by_last_sort"])
+        proof["ran_as_recorded"] = ran_as_recorded(plan, proof)
+        if not proof["ran_as_recorded"]:
+            print(f"[bench] {mode}: the device turned the recorded {plan.name} plan down in the timed region: {proof}", file=sys.stderr)
+    bytes_keys = bytes_moved_per_item(plan_keys, proof_keys["ran_as_recorded"])
+    bytes_kv = bytes_moved_per_item(plan_kv, proof_kv["ran_as_recorded"])
 
     def dominant(kernels):
         movers = {k: v for k, v in kernels.items() if v["algorithmic_bytes_per_launch"] > 0 and k != "histogram"}
