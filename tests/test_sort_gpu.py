@@ -430,6 +430,67 @@ def test_capturable_into_a_hip_graph(torch_mod, sorter, oracle):
         assert sorter.read_status(torch.cuda.current_stream().cuda_stream, storage.data_ptr(), 0) == 0
 
 
+def test_one_captured_graph_sorts_whatever_keys_it_is_replayed_on(torch_mod, sorter, oracle):
+    """Record once, submit many (the reference's model, bench/vulkan_benchmark.cc:292-302) at a size that records the MSD plan:
+    what the plan does is decided on the DEVICE at every replay -- where the scatter's window lies, whether the plan runs at
+    all -- so ONE captured sort must be right for uniform keys (window at the top), 24-bit keys (window below a prefix),
+    descending ids, all-identical keys (verdict 4: nothing moved), four distinct values and a broken prefix (both: the four
+    passes), replayed in that order on the same buffers, keys-only and key+value."""
+    import vulkan_radix_sort_amd as vrdx
+    torch = torch_mod
+    n = 9_000_017
+    rng = np.random.default_rng(5)
+    r = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+    iota = np.arange(n, dtype=np.uint32)
+    broken = (r >> np.uint32(8)).copy()
+    broken[n // 2 + 3] |= np.uint32(0x80000000)
+    inputs = [("uniform", r, vrdx.VERDICT_MSD_RUNS), ("24-bit", r >> np.uint32(8), vrdx.VERDICT_MSD_RUNS),
+              ("descending", (n - 1 - iota).astype(np.uint32), vrdx.VERDICT_MSD_RUNS),
+              ("all equal", np.full(n, 0xCAFEF00D, np.uint32), vrdx.VERDICT_MSD_SORTED),
+              ("four values", np.array([7, 0xFFFFFFFF, 0x00020000, 0x7E000000], np.uint32)[rng.integers(0, 4, n)], vrdx.VERDICT_NONE),
+              ("broken prefix", broken, vrdx.VERDICT_NONE), ("uniform again", r[::-1].copy(), vrdx.VERDICT_MSD_RUNS)]
+    stream = torch.cuda.current_stream().cuda_stream
+    for key_value in (False, True):
+        assert sorter.describe_plan(n, key_value).name == "msd"
+        dk, dv = _u32_to_dev(torch, r), _u32_to_dev(torch, iota)
+        size = (sorter.key_value_storage_requirements(n) if key_value else sorter.storage_requirements(n)).size
+        storage = torch.empty(size, dtype=torch.uint8, device="cuda")
+        record = ((lambda st: sorter.cmd_sort_key_value(st, n, dk.data_ptr(), 0, dv.data_ptr(), 0, storage.data_ptr(), 0))
+                  if key_value else (lambda st: sorter.cmd_sort(st, n, dk.data_ptr(), 0, storage.data_ptr(), 0)))
+        record(stream)   # (one eager sort first, see test_capturable_into_a_hip_graph)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            record(torch.cuda.current_stream().cuda_stream)
+        for name, k, verdict in inputs:
+            dk.copy_(_u32_to_dev(torch, k))
+            dv.copy_(_u32_to_dev(torch, iota))
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            ek, ep, _ = oracle.sort(k, iota)
+            assert np.array_equal(_to_u32(dk), ek), (name, key_value)
+            assert not key_value or np.array_equal(_to_u32(dv), ep), (name, key_value)
+            assert sorter.read_plan_verdict(stream, storage.data_ptr(), 0) == verdict, (name, key_value)
+            assert sorter.read_status(stream, storage.data_ptr(), 0) == 0
+
+
+@pytest.mark.parametrize("key_value", [False, True])
+def test_two_tile_scatter_at_its_tile_boundaries(torch_mod, sorter, oracle, key_value):
+    """The keys-only scatter of the ten-bit MSD plan takes two consecutive tiles per workgroup and stages them in two halves
+    (vrdx_kernels.hip, ScatterMsdPairBody): device-side counts that end exactly at, one before and one behind a tile, a
+    pair of tiles, and the middle of either half -- with the bound at 2^25 (tiles of 32768 keys) and at a size whose tiles
+    are smaller and odd in number (18149377: 739 tiles of 24576).  Key+value (one tile per workgroup) for comparison."""
+    for bound in (1 << 25, 18_149_377):
+        k, _ = oracle.generate(17, bound, 32)
+        v = np.arange(bound, dtype=np.uint32) if key_value else None
+        tile = 32768 if bound == 1 << 25 else 24576
+        base = 200 * 2 * tile
+        for count in (base, base - 1, base + 1, base + tile, base + tile - 1, base + tile + 1, base + tile // 2,
+                      base + tile + tile // 2 + 5, bound - 1, bound):
+            check_against_oracle(torch_mod, sorter, oracle, k, v, count=count, indirect=True, max_count=bound)
+
+
 def _random_cases(count, seed):
     """(n, bits, key+value, indirect, count) drawn from a fixed stream: sizes log-uniform over 1 .. 3 M (every
     path: single workgroup, 1024x8 / x16 / x32 tiles), keys of 0 .. 32 significant bits (0, 8, 16, 24: passes
