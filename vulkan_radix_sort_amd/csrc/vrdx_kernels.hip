@@ -2751,7 +2751,7 @@ constexpr size_t BucketSort2LdsWords() {
 }
 
 template <uint32_t BITS, int KPT, bool KV, int THREADS = 1024>
-__device__ __forceinline__ void BucketSort2Body(const MsdArgs a) {
+__device__ __forceinline__ void BucketSort2Bucket(const MsdArgs a, const uint32_t bucket, const uint32_t below) {
   constexpr int WAVES = THREADS / 64;
   static_assert(THREADS == 1024 || THREADS == 512, "one or two words of a counter row per thread");
   constexpr uint32_t TILE = THREADS * KPT;
@@ -2766,18 +2766,15 @@ __device__ __forceinline__ void BucketSort2Body(const MsdArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const uint32_t verdict = *a.planWord;
-  if ((verdict & kMsdVerdictMask) != kMsdVerdictRuns) return;  // the plan does not apply (the four passes are running), or nothing needs sorting
   // The bits below the scatter's window, two to twenty-two (the window never lies lower than bit 2), in TWO passes of half
   // the bits each: 11 | 11 under the top window of uniform keys.  (11 | 4 for the fifteen bits of dense 25-bit ids measured
   // 146 us against 120: sixteen digits are eight counter words for 64 lanes, an eight-way conflict in every atomic of the
   // second pass; 8 | 7 has none.  And always two passes, also where one would do: with a run-time number of passes the same
   // loop ran 115 us instead of 108 for uniform keys.)
-  const uint32_t below = (verdict >> kMsdShiftShift) & kMsdShiftMask;
   const uint32_t W0 = (below + 1u) / 2u, W1 = below / 2u;
   constexpr uint32_t passes = 2u;
-  const uint32_t myBase = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.bucketBase[blockIdx.x]);
-  const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.bucketCount[blockIdx.x]);
+  const uint32_t myBase = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.bucketBase[bucket]);
+  const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.bucketCount[bucket]);
   if (n == 0) return;
   const uint32_t* const keysIn = a.keysScratch + myBase;
   uint32_t* const keysOut = a.keysCaller + myBase;
@@ -2913,6 +2910,19 @@ __device__ __forceinline__ void BucketSort2Body(const MsdArgs a) {
       }
     }
   }
+}
+
+// The bucket launch: workgroup b sorts bucket b, b + grid, ... -- one bucket per workgroup when the grid is 2^BITS (the launches
+// of their own), two when it is half that: the keys-only launch that is also pass 1 of the fallback then carries no
+// workgroups the pass has no tile for (1024 workgroups of 144 KiB of LDS for 512 tiles cost a turned-down sort 3-6 us).
+// (Every pass of a bucket ends with a barrier: the next bucket may clear its counters where the staging buffer was.)
+template <uint32_t BITS, int KPT, bool KV, int THREADS = 1024>
+__device__ __forceinline__ void BucketSort2Body(const MsdArgs a) {
+  const uint32_t verdict = *a.planWord;
+  if ((verdict & kMsdVerdictMask) != kMsdVerdictRuns) return;  // the plan does not apply (the four passes are running), or nothing needs sorting
+  const uint32_t below = (verdict >> kMsdShiftShift) & kMsdShiftMask;
+#pragma unroll 1
+  for (uint32_t bucket = blockIdx.x; bucket < (1u << BITS); bucket += gridDim.x) BucketSort2Bucket<BITS, KPT, KV, THREADS>(a, bucket, below);
 }
 
 template <uint32_t BITS, bool KV>
@@ -3476,12 +3486,18 @@ hipError_t LaunchScatterMsd(hipStream_t stream, bool keyValue, const MsdArgs& ar
   return Launch(kernel, MsdScatterGrid(args.tiles, keyValue, args.bits), 1024, lds, stream, args);
 }
 
+// Workgroups of the plan's bucket launch.  The full-size kernel (one workgroup per CU) takes TWO buckets per workgroup, one
+// after the other (BucketSort2Body): half as many workgroups to start and to drain -- 107.4 instead of 110.9 us keys-only at
+// 2^25, 175-178 instead of 179-180 key+value (tools/r06/bucket_grid.sh, bucket_grid2.sh).  The half-size kernel (two
+// workgroups per CU) keeps one: 47.7 against 47.0 us keys-only at 2^24 with two.
+static uint32_t MsdBucketGrid(uint32_t bits, bool halfSizeKernel) { return halfSizeKernel ? 1u << bits : (1u << bits) / 2u; }
+
 hipError_t LaunchBucketSort2(hipStream_t stream, bool keyValue, const MsdArgs& args) {
   constexpr int kKeys = kMsdCapKeys / 1024, kPairs = kMsdCapKeyValue / 1024;
   if (args.cap == kMsdHalfCap && args.bits == 10) {
     const void* half = keyValue ? reinterpret_cast<const void*>(&bucket_sort2_half_kernel<10, true>)
                                 : reinterpret_cast<const void*>(&bucket_sort2_half_kernel<10, false>);
-    return Launch(half, 1u << args.bits, 512, BucketSort2LdsWords<kMsdHalfCap / 512, 512>() * 4, stream, args);
+    return Launch(half, MsdBucketGrid(args.bits, true), 512, BucketSort2LdsWords<kMsdHalfCap / 512, 512>() * 4, stream, args);
   }
   if (args.cap != (keyValue ? kMsdCapKeyValue : kMsdCapKeys)) return hipErrorInvalidValue;
   const void* kernel;
@@ -3494,7 +3510,7 @@ hipError_t LaunchBucketSort2(hipStream_t stream, bool keyValue, const MsdArgs& a
   else
     return hipErrorInvalidValue;
   const size_t lds = (keyValue ? BucketSort2LdsWords<kPairs>() : BucketSort2LdsWords<kKeys>()) * 4;
-  return Launch(kernel, 1u << args.bits, 1024, lds, stream, args);
+  return Launch(kernel, MsdBucketGrid(args.bits, false), 1024, lds, stream, args);
 }
 
 // The plan's scatter / bucket launch with the fallback's pass 0 / pass 1 as its second role (bucketLaunch selects which).
@@ -3509,7 +3525,8 @@ static hipError_t LaunchMsdFusedBits(hipStream_t stream, bool bucketLaunch, cons
                           : reinterpret_cast<const void*>(&msd_scatter_or_pass0_kernel<BITS, KV, false>));
   // the larger of the two roles' grids, a multiple of 8 (the scatter derives its tile from the grid: eight chunks of tiles, one
   // per XCD; a workgroup beyond its role's range returns)
-  const uint32_t planGrid = bucketLaunch ? (1u << BITS) : MsdScatterGrid(m.tiles, KV, BITS);
+  // (the bucket launch: two buckets per workgroup, MsdBucketGrid -- a pass of up to 2^BITS / 2 tiles then has no idle workgroups)
+  const uint32_t planGrid = bucketLaunch ? MsdBucketGrid(BITS, false) : MsdScatterGrid(m.tiles, KV, BITS);
   const uint32_t grid = 8u * (((planGrid > passGrid ? planGrid : passGrid) + 7u) / 8u);
   // the pass's run-time slot counts, checked like LaunchPairConfig / LaunchConfig do
   if (dyn && (p.slots % 4 != 0 || p.slots > 32u || p.tailSlots % 4 != 0 || p.tailSlots == 0 || p.tailSlots > 32u))
