@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: needs the experiment build in front of commit a1208b4 (VRDX_X_BUCKET_GRID=1 selected one bucket per workgroup); the product has no such knob.
 # The keys-only bucket launch that is also pass 1 of the fallback: 512 workgroups of two buckets each (default) against 1024 of one
 # (VRDX_X_BUCKET_GRID=1, experiment knob of the build under test): uniform keys (the bucket role) and inputs the device turns down (the pass role).
 ROOT=$(cd "$(dirname "$0")/../.." && pwd); OUT=$ROOT/gpurun_out/${TAG:-r06_bucket_grid}; mkdir -p $OUT

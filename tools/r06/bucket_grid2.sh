@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: needs the experiment build in front of commit a1208b4 (VRDX_X_BUCKET_GRID=1 selected one bucket per workgroup); the product has no such knob.
 # Two buckets per workgroup in the bucket launches of their own (key+value; the half-size kernel) against one (VRDX_X_BUCKET_GRID=1).
 ROOT=$(cd "$(dirname "$0")/../.." && pwd); OUT=$ROOT/gpurun_out/${TAG:-r06_bucket_grid2}; mkdir -p $OUT
 export TMPDIR=/tmp
