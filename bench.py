@@ -172,7 +172,7 @@ def stage_profile(torch, sorter, pristine, n, key_value, device, repeats=5):
     STAMPED, i.e. each including one event record (main() subtracts the calibrated cost of that,
     vrdxHipEventOverheadNs, to get kernel time).  Returns a dict of mean intervals in ms:
       the MSD plan      {"histogram", "spine", "scatter", "bucket", "fallback"}  (slots 1-2, 2-3, 3-4, 4-5, 5-14: the
-                        four launches of the fallback, which return on the plan's verdict)
+                        launches of the fallback that are not also a launch of the plan; they return on its verdict)
       the four passes   {"histogram", "sweep"}  (slots 1-2 and the mean of the four downsweep intervals)
     The stamped sort runs right BEHIND another sort of a different array, like every sort of the timed region does: a
     kernel is charged for the write-back of what the kernel before it has just written, and with
@@ -631,14 +631,19 @@ def main():
         if plan.name == "msd":
             names = {"histogram": "histogram_msd_kernel<32u, %du>" % plan.bits,
                      "spine": "spine_msd_kernel<%du>" % plan.bits,
-                     # keys-only: the plan's scatter / bucket launches are also pass 0 / pass 1 of the fallback (one kernel,
-                     # two roles chosen on the device); two passes remain as launches that return on the verdict
-                     "scatter": ("scatter_msd_kernel<%du, true>" % plan.bits) if key_value
-                                else ("msd_scatter_or_pass0_kernel<%du, false, false>" % plan.bits),
-                     "bucket": ("bucket_sort2_kernel<%du, 36, true>" % plan.bits) if key_value
-                               else ("msd_buckets_or_pass1_kernel<%du, false, false>" % plan.bits),
-                     "fallback": ("4 x " if key_value else "2 x ") + kernel_name(version, "key-value" if key_value else "keys")
-                                 + " (returning on the verdict)"}
+                     # the plan's scatter / bucket launches are also pass 0 / pass 1 of the fallback (one kernel, two roles
+                     # chosen on the device); the other passes remain as launches that return on the verdict.  How many
+                     # launches have a second role (0 | 1 | 2) is in the plan's launch count: histogram + spine + scatter +
+                     # buckets + the passes that are launches of their own
+                     "fallback": None}
+            fused = 8 - int(plan.launches)
+            kv = "true" if key_value else "false"
+            names["scatter"] = ("msd_scatter_or_pass0_kernel<%du, %s, false>" % (plan.bits, kv)) if fused >= 1 \
+                else ("scatter_msd_kernel<%du, %s>" % (plan.bits, kv))
+            names["bucket"] = ("msd_buckets_or_pass1_kernel<%du, %s, false>" % (plan.bits, kv)) if fused >= 2 \
+                else ("bucket_sort2_kernel<%du, 36, %s>" % (plan.bits, kv))
+            names["fallback"] = ("%d x " % (4 - fused)) + kernel_name(version, "key-value" if key_value else "keys") \
+                + " (returning on the verdict)"
             bytes_of = {"histogram": 4.0 * n, "spine": 0.0, "scatter": 2 * item * n, "bucket": 2 * item * n, "fallback": 0.0}
             what = {"histogram": "HBM read", "spine": "launch latency (4 MiB of 16-bit counts)",
                     "scatter": "HBM read + write in runs of 128 bytes", "bucket": "LDS (two in-LDS passes per key between one read and one write)",

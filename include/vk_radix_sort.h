@@ -144,9 +144,11 @@ void vrdxGetSorterKeyValueStorageRequirements(VrdxSorter sorter, uint32_t maxEle
  *                 when the device takes the plan
  *   MSD           [1,2] histogram (it also chooses the window); [2,3] spine; [3,4] scatter by the
  *                 window bits; [4,5] one workgroup per bucket; the passes that are launches of their own follow
- *                 and return at once when the device takes the plan: [9,10] pass 2, [12,13] pass 3, and for key+value
- *                 sorts [6,7] passes 0 and 1 together (keys-only: passes 0 and 1 are second roles of the scatter and
- *                 bucket launches -- when the device turns the plan down, [3,4] and [4,5] ARE passes 0 and 1)
+ *                 and return at once when the device takes the plan: [9,10] pass 2, [12,13] pass 3, and [6,7] pass 1
+ *                 where it is a launch (sorts of up to 18.1 M elements: the half-size bucket kernel has no second
+ *                 role).  Passes 0 and 1 are otherwise second roles of the scatter and bucket launches -- when the
+ *                 device turns the plan down, [3,4] and [4,5] ARE passes 0 and 1 (with VRDX_MSD_FUSED=0 in the
+ *                 environment they are launches of their own again, both inside [6,7])
  *   ONE_WORKGROUP [13,14] the one kernel
  */
 void vrdxCmdSort(VkCommandBuffer commandBuffer, VrdxSorter sorter, uint32_t elementCount,

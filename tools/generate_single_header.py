@@ -56,8 +56,8 @@ def expected_kernels():
         names += ["_ZN4vrdx20histogram_msd_kernelILj%dELj%dEEEvNS_7MsdArgsE" % (c, bits) for c in (8, 32)]
         names += ["_ZN4vrdx18scatter_msd_kernelILj%dELb%dEEEvNS_7MsdArgsE" % (bits, kv) for kv in (0, 1)]
         names += ["_ZN4vrdx19bucket_sort2_kernelILj%dELi36ELb%dEEEvNS_7MsdArgsE" % (bits, kv) for kv in (0, 1)]
-        for kernel in ("27msd_scatter_or_pass0_kernel", "27msd_buckets_or_pass1_kernel"):  # keys-only: the plan's launch or a pass of its fallback
-            names += ["_ZN4vrdx%sILj%dELb0ELb%dEEEvNS_7MsdArgsENS_12OnesweepArgsE" % (kernel, bits, dyn) for dyn in (0, 1)]
+        for kernel in ("27msd_scatter_or_pass0_kernel", "27msd_buckets_or_pass1_kernel"):  # the plan's launch or a pass of its fallback
+            names += ["_ZN4vrdx%sILj%dELb%dELb%dEEEvNS_7MsdArgsENS_12OnesweepArgsE" % (kernel, bits, kv, dyn) for kv in (0, 1) for dyn in (0, 1)]
     for kv in (0, 1):  # 32768-element buckets: one-atomic ranking only
         names.append("_ZN4vrdx18bucket_sort_kernelILi1024ELi32ELb%dELb1EEEvNS_14BucketSortArgsE" % kv)
     for kpt in (4, 8, 16):

@@ -395,12 +395,12 @@ SortPlan PlanSort(const VrdxSorter_T* sorter, bool keyValue, uint32_t elementCou
   }
   // The MSD plan's scatter launch is ALSO pass 0 of the fallback and its bucket launch pass 1 (one branch on the verdict, on
   // the device): only passes 2 and 3 remain as launches that return when the plan runs.  The fused kernels exist for the
-  // geometry the recorder selects at these sizes (ConfigIndex: the two-sub-tile kernel), keys-only (the key+value form
-  // measured slower than the launches it saves, vrdx_kernels.hip); with buckets of the half-size kernel (512 threads; the
+  // geometries the recorder selects at these sizes (ConfigIndex: the two-sub-tile kernel keys-only, 1024x32 key+value --
+  // since round 6: vrdx_kernels.hip, msd_scatter_or_pass0_kernel); with buckets of the half-size kernel (512 threads; the
   // passes' bodies need 1024) only the scatter launch has a second role.  VRDX_MSD_FUSED=0: none (measurements).
   static const int fusedKnob = TuningKnob("VRDX_MSD_FUSED");
-  if (p.msdBits != 0 && !keyValue && p.configIndex == kCfg1024x32x2 && fusedKnob != 0)
-    p.msdFused = p.msdCap == vrdx::kMsdCapKeys ? 2u : 1u;
+  if (p.msdBits != 0 && fusedKnob != 0 && p.configIndex == (keyValue ? kCfg1024x32 : kCfg1024x32x2))
+    p.msdFused = p.msdCap == (keyValue ? vrdx::kMsdCapKeyValue : vrdx::kMsdCapKeys) ? 2u : 1u;
   // kernels: histogram + four passes (+ the eight-bit plan's bucket launch); the MSD plan: + spine, and those of its scatter
   // and bucket launches that are not also a pass
   p.launches = 1u + VRDX_PASSES + (p.msdBits != 0 ? 3u - p.msdFused : 0u) + (p.hybridCap != 0 ? 1u : 0u);

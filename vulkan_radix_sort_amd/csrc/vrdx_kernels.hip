@@ -2912,17 +2912,17 @@ __device__ __forceinline__ void BucketSort2Bucket(const MsdArgs a, const uint32_
   }
 }
 
-// The bucket launch: workgroup b sorts bucket b, b + grid, ... -- one bucket per workgroup when the grid is 2^BITS (the launches
-// of their own), two when it is half that: the keys-only launch that is also pass 1 of the fallback then carries no
+// The bucket launch: workgroup b sorts bucket b, b + workgroups, ... -- one bucket per workgroup when there are 2^BITS of them
+// (the half-size kernel), two when half that: the keys-only launch that is also pass 1 of the fallback then carries no
 // workgroups the pass has no tile for (1024 workgroups of 144 KiB of LDS for 512 tiles cost a turned-down sort 3-6 us).
 // (Every pass of a bucket ends with a barrier: the next bucket may clear its counters where the staging buffer was.)
 template <uint32_t BITS, int KPT, bool KV, int THREADS = 1024>
-__device__ __forceinline__ void BucketSort2Body(const MsdArgs a) {
+__device__ __forceinline__ void BucketSort2Body(const MsdArgs a, const uint32_t workgroups) {
   const uint32_t verdict = *a.planWord;
   if ((verdict & kMsdVerdictMask) != kMsdVerdictRuns) return;  // the plan does not apply (the four passes are running), or nothing needs sorting
   const uint32_t below = (verdict >> kMsdShiftShift) & kMsdShiftMask;
 #pragma unroll 1
-  for (uint32_t bucket = blockIdx.x; bucket < (1u << BITS); bucket += gridDim.x) BucketSort2Bucket<BITS, KPT, KV, THREADS>(a, bucket, below);
+  for (uint32_t bucket = blockIdx.x; bucket < (1u << BITS); bucket += workgroups) BucketSort2Bucket<BITS, KPT, KV, THREADS>(a, bucket, below);
 }
 
 template <uint32_t BITS, bool KV>
@@ -2931,7 +2931,7 @@ __global__ __launch_bounds__(1024) void scatter_msd_kernel(MsdArgs a) {
 }
 template <uint32_t BITS, int KPT, bool KV>
 __global__ __launch_bounds__(1024) void bucket_sort2_kernel(MsdArgs a) {
-  BucketSort2Body<BITS, KPT, KV>(a);
+  BucketSort2Body<BITS, KPT, KV>(a, gridDim.x);
 }
 // Buckets of no more than 18432 elements (sorts of up to 18.1 M elements by ten bits): workgroups of 512 threads and
 // 72 KiB of LDS, TWO to a CU -- one loads or scans while the other ranks.  A bucket has a fixed cost of 5.7 us in the
@@ -2941,21 +2941,20 @@ __global__ __launch_bounds__(1024) void bucket_sort2_kernel(MsdArgs a) {
 // 128 registers; the kernels take 85 keys-only and 121 key+value.)
 template <uint32_t BITS, bool KV>
 __global__ __launch_bounds__(512, 4) void bucket_sort2_half_kernel(MsdArgs a) {
-  BucketSort2Body<BITS, kMsdHalfCap / 512, KV, 512>(a);
+  BucketSort2Body<BITS, kMsdHalfCap / 512, KV, 512>(a, gridDim.x);
 }
 
 // ---- the plan's launches double as the first two launches of its fallback ------------------------------
 // Behind the MSD plan the four passes are recorded as the fallback for keys the device turns the plan down for; when the plan
-// runs they return on the verdict word -- 4.1 us each at 2^25 (512 workgroups of 156 KiB of LDS and one load), 16 us of a
-// 260 us sort.  Two of the four are saved by giving the plan's own launches a second ROLE: the scatter launch is pass 0 of
-// the fallback when a bucket exceeds the capacity, the bucket launch is pass 1 when the scatter has not run -- one branch on
-// a word every workgroup reads anyway, the grid the larger of the two roles' (a workgroup beyond its role's range returns:
-// both bodies check).  The pass is the one the recorder would have launched at these sizes: the two-sub-tile kernel
-// keys-only, the one-atomic ranking (the plan is recorded with it only), DYN by the tile plan.  Passes 2 and 3 stay launches
-// of their own.  KEYS-ONLY sorts only: 0.2520 instead of 0.2610 ms at 2^25.  The key+value form (the plan's kernels fused with
-// onesweep_kernel<1024, 32, kv>) was built and measured as well: its scatter role ran 16 us SLOWER than scatter_msd_kernel
-// alone (163.6 against 147.6 us; the compiler leaves it a private segment of 36 bytes that no instruction touches, and with
-// it a scratch set-up per wave) -- more than the two launches save.  Not instantiated.
+// runs they return on the verdict word -- 4.4 us each at 2^25 (512-1024 workgroups of 144-156 KiB of LDS and one load), 18 us
+// of a 400 us key+value sort.  Two of the four are saved by giving the plan's own launches a second ROLE: the scatter launch is
+// pass 0 of the fallback when the plan is turned down, the bucket launch is pass 1 when the scatter has not run -- one branch
+// on a word every workgroup reads anyway, the grid the larger of the two roles' (a workgroup beyond its role's range returns:
+// both bodies check).  The pass is the one the recorder would have launched at these sizes: the two-sub-tile kernel keys-only,
+// onesweep_kernel<1024, 32, kv> key+value, the one-atomic ranking (the plan is recorded with it only), DYN by the tile plan.
+// Passes 2 and 3 stay launches of their own.  Keys-only since round 5 (0.2520 instead of 0.2610 ms at 2^25); the key+value
+// form measured 16 us SLOWER in its scatter role then (a private segment of 36 bytes that no instruction touches, and with
+// it a scratch set-up per wave) and waited for round 6, which found that segment to be a matter of the kernels' shape (below).
 template <uint32_t BITS, bool KV, bool DYN>
 __device__ __forceinline__ void FallbackPassBody(const OnesweepArgs p) {
   if constexpr (KV)
@@ -2973,22 +2972,32 @@ constexpr size_t MsdFusedLdsWords(uint32_t bits, bool bucketLaunch) {
 
 template <uint32_t BITS, bool KV, bool DYN>
 __global__ __launch_bounds__(1024) void msd_scatter_or_pass0_kernel(MsdArgs m, OnesweepArgs p) {
+  // (The SHAPE of these two kernels is not free: with the key+value pass body inside -- 106 SGPRs, 70 of them spilled to VGPR
+  // lanes -- an if / else of the two roles, or the counter in front of the pass, leaves a 36-byte private segment that no
+  // instruction touches and a scratch set-up per wave with it (round 5: 16 us in the scatter role); "the plan's role and
+  // return, then the pass, then the counter" and, below, "the pass first" compile without.  tests/test_abi.py watches it.)
   if ((*m.overflowWord & kMsdDeclineMask) == 0u) {
     ScatterMsdRole<BITS, KV>(m);
-  } else {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && m.declinedPlans != nullptr) atomicAdd(m.declinedPlans, 1u);
-    // (the grid is the larger of the two roles': a workgroup beyond the pass's tiles has no ticket to take)
-    if (blockIdx.x > p.statusRows) return;
-    FallbackPassBody<BITS, KV, DYN>(p);
+    return;
   }
+  // (the grid is the larger of the two roles': a workgroup beyond the pass's tiles has no ticket to take)
+  if (blockIdx.x > p.statusRows) return;
+  FallbackPassBody<BITS, KV, DYN>(p);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && m.declinedPlans != nullptr) atomicAdd(m.declinedPlans, 1u);  // (vrdxHipReadPlanCounters)
 }
 template <uint32_t BITS, bool KV, bool DYN>
 __global__ __launch_bounds__(1024) void msd_buckets_or_pass1_kernel(MsdArgs m, OnesweepArgs p) {
   const uint32_t verdict = *m.planWord & kMsdVerdictMask;
-  if (verdict == kMsdVerdictRuns)
-    BucketSort2Body<BITS, (KV ? kMsdCapKeyValue : kMsdCapKeys) / 1024, KV>(m);
-  else if (verdict != kMsdVerdictSorted && blockIdx.x <= p.statusRows)
+  if (verdict < kMsdVerdictRuns) {  // the plan was turned down: pass 1 of the four
+    if (blockIdx.x > p.statusRows) return;
     FallbackPassBody<BITS, KV, DYN>(p);
+    return;
+  }
+  // (two buckets per workgroup whatever the pass's grid is: with key+value tiles of 32768 the pass has as many tiles as the plan
+  // has buckets, and 1032 workgroups of one bucket each measured 182 us where 512 of two take 173)
+  const uint32_t workgroups = min(gridDim.x, (1u << BITS) / 2u);
+  if (verdict == kMsdVerdictRuns && blockIdx.x < workgroups)
+    BucketSort2Body<BITS, (KV ? kMsdCapKeyValue : kMsdCapKeys) / 1024, KV>(m, workgroups);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3418,6 +3427,10 @@ static hipError_t PrepareMsdBits() {
       {reinterpret_cast<const void*>(&msd_scatter_or_pass0_kernel<BITS, false, true>), MsdFusedLdsWords<false>(BITS, false) * 4},
       {reinterpret_cast<const void*>(&msd_buckets_or_pass1_kernel<BITS, false, false>), MsdFusedLdsWords<false>(BITS, true) * 4},
       {reinterpret_cast<const void*>(&msd_buckets_or_pass1_kernel<BITS, false, true>), MsdFusedLdsWords<false>(BITS, true) * 4},
+      {reinterpret_cast<const void*>(&msd_scatter_or_pass0_kernel<BITS, true, false>), MsdFusedLdsWords<true>(BITS, false) * 4},
+      {reinterpret_cast<const void*>(&msd_scatter_or_pass0_kernel<BITS, true, true>), MsdFusedLdsWords<true>(BITS, false) * 4},
+      {reinterpret_cast<const void*>(&msd_buckets_or_pass1_kernel<BITS, true, false>), MsdFusedLdsWords<true>(BITS, true) * 4},
+      {reinterpret_cast<const void*>(&msd_buckets_or_pass1_kernel<BITS, true, true>), MsdFusedLdsWords<true>(BITS, true) * 4},
   };
   for (const auto& k : fused) {
     const hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.bytes);
@@ -3536,10 +3549,15 @@ static hipError_t LaunchMsdFusedBits(hipStream_t stream, bool bucketLaunch, cons
 
 hipError_t LaunchMsdFused(hipStream_t stream, bool bucketLaunch, bool keyValue, const MsdArgs& m, const OnesweepArgs& p,
                           uint32_t passGrid) {
-  if (keyValue || m.tileKeys == 0 || m.tileKeys % 4096u != 0 || m.tileKeys > kMsdTileKeys || (bucketLaunch && m.cap != kMsdCapKeys))
-    return hipErrorInvalidValue;  // keys-only sorts only
-  if (m.bits == 10) return LaunchMsdFusedBits<10, false>(stream, bucketLaunch, m, p, passGrid);
-  if (m.bits == 11) return LaunchMsdFusedBits<11, false>(stream, bucketLaunch, m, p, passGrid);
+  if (m.tileKeys == 0 || m.tileKeys % 4096u != 0 || m.tileKeys > kMsdTileKeys ||
+      (bucketLaunch && m.cap != (keyValue ? kMsdCapKeyValue : kMsdCapKeys)))
+    return hipErrorInvalidValue;
+  if (m.bits == 10)
+    return keyValue ? LaunchMsdFusedBits<10, true>(stream, bucketLaunch, m, p, passGrid)
+                    : LaunchMsdFusedBits<10, false>(stream, bucketLaunch, m, p, passGrid);
+  if (m.bits == 11)
+    return keyValue ? LaunchMsdFusedBits<11, true>(stream, bucketLaunch, m, p, passGrid)
+                    : LaunchMsdFusedBits<11, false>(stream, bucketLaunch, m, p, passGrid);
   return hipErrorInvalidValue;
 }
 
