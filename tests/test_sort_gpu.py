@@ -672,6 +672,10 @@ def test_msd_plan_and_its_fallback_at_the_bucket_capacity(torch_mod, sorter, ora
     bits = int(info.bits)
     cap = msd_capacity(n, bits)
     assert cap == (18432 if n <= MSD_HALF_UP_TO else 36864)
+    # launches: histogram, spine, scatter, buckets and the passes of the fallback that are launches of their own -- the scatter
+    # launch is also pass 0, and the full-size bucket launch pass 1 (keys-only since round 5, key+value since round 6)
+    if "VRDX_MSD_FUSED" not in os.environ and "VRDX_TILE_CONFIG" not in os.environ:
+        assert info.launches == (7 if n <= MSD_HALF_UP_TO else 6), info.launches
     shift, low = np.uint32(32 - bits), np.uint32((1 << (32 - bits)) - 1)
     bucket = 0x155
     rng = np.random.default_rng(n)
