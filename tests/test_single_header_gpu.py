@@ -53,3 +53,15 @@ def test_single_header_passes_the_native_parity_battery():
     assert "libvrdx_hip" not in ldd and "libamdhip64" in ldd
     r = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and ", 0 failures" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_single_header_passes_the_msd_battery():
+    """The MSD plan through the single header's own launcher (vrdx_module_launch.inc: hipModuleLaunchKernel by mangled name,
+    its grids and LDS sizes restated there) -- the sizes the quick battery stops short of: both bucket kernels, both
+    windows, the plan's launches in their second role as passes 0 and 1 (keys-only and key+value), every verdict."""
+    _header()
+    exe = os.path.join(NATIVE, "selftest_single_header")
+    subprocess.run(["make", "-C", NATIVE, "selftest_single_header"], check=True, capture_output=True)
+    r = subprocess.run([exe, "msd"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and ", 0 failures" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
